@@ -1,0 +1,127 @@
+"""ctypes binding of libgsr_hip.so (C ABI declared in include/gsr_hip.h).
+
+This is the only place the product path touches native code.  There is NO CPU fallback: if the
+library is missing or cannot be loaded, importing the rasterizer packages fails loudly.
+torch is used for device memory, streams and autograd plumbing only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+c_void_p, c_int, c_float, c_size_t, c_uint32, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
+                                                         ctypes.c_uint32, ctypes.c_char_p)
+ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_int, c_size_t)
+
+GSR_BUF_GEOM, GSR_BUF_BINNING, GSR_BUF_IMAGE = 0, 1, 2
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            f"`python {os.path.join(_HERE, 'csrc', 'build.py')}` (hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P = c_void_p
+    lib.gsr_last_error.restype = c_char_p
+    lib.gsr_version.restype = c_int
+    lib.gsr_surfel_forward.restype = c_int
+    lib.gsr_surfel_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
+                                       c_float, c_float, c_int, P, P, P, P, P, c_int, P]
+    lib.gsr_surfel_backward.restype = c_int
+    lib.gsr_surfel_backward.argtypes = [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float,
+                                        P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]
+    lib.gsr_gauss_forward.restype = c_int
+    lib.gsr_gauss_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
+                                      c_float, c_float, c_int, P, P, P, P, c_int, P, c_int, P]
+    lib.gsr_gauss_backward.restype = c_int
+    lib.gsr_gauss_backward.argtypes = [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P, c_float,
+                                       c_float, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]
+    lib.gsr_mark_visible.restype = c_int
+    lib.gsr_mark_visible.argtypes = [c_int, P, P, P, P, P]
+    lib.gsr_debug_fetch.restype = c_int
+    lib.gsr_debug_fetch.argtypes = [c_int, c_char_p, c_int, c_int, c_int, c_int, P, P, P, P, P]
+    lib.gsr_cubemap_forward.restype = c_int
+    lib.gsr_cubemap_forward.argtypes = [P, P, P, P, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, P]
+    lib.gsr_cubemap_backward.restype = c_int
+    lib.gsr_cubemap_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, P]
+    lib.gsr_deferred_reflection_forward.restype = c_int
+    lib.gsr_deferred_reflection_forward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P]
+    lib.gsr_deferred_reflection_backward.restype = c_int
+    lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P]
+    return lib
+
+
+lib = _load()
+
+EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
+            "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
+            "gsr_deferred_reflection_backward"]
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = lib.gsr_last_error()
+        raise GsrError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the reference passes
+    `.contiguous().data<float>()`, which is nullptr for empty tensors, and tests `== nullptr`)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t, name):
+    # CHECK_INPUT of DSR rasterize_points.cu:27-28
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def f32c(t, name):
+    """Contiguous float32 view (reference: `.contiguous().data<float>()` throws on other dtypes)."""
+    if t.numel() and t.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {t.dtype} for {name}")
+    return t.contiguous()
+
+
+class Workspace:
+    """The three opaque byte buffers of one forward call (geomBuffer, binningBuffer, imgBuffer of
+    DSR rasterize_points.cu:102-108), allocated by torch when the library asks for them."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.error = None
+
+        def _alloc(user, which, nbytes):
+            try:
+                t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+                self.bufs[which] = t
+                return t.data_ptr()
+            except Exception as e:  # surfaced as GSR_E_ALLOC by the library
+                self.error = e
+                return 0
+
+        self.cb = ALLOC_FN(_alloc)
+
+
+def debug_fetch(variant, name, P, R, W, H, geom, binning, img, dtype, shape):
+    """Parity-test helper: copy a named workspace array out (see gsr_debug_fetch in gsr_hip.h)."""
+    out = torch.empty(shape, dtype=dtype, device=geom.device)
+    check(lib.gsr_debug_fetch(variant, name.encode(), P, R, W, H, ptr(geom), ptr(binning), ptr(img), ptr(out) if out.numel() else None,
+                              stream_ptr(geom.device)), f"gsr_debug_fetch({name})")
+    return out

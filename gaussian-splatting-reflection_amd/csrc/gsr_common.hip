@@ -1,0 +1,266 @@
+// Shared host plumbing + the binning pipeline (tile/depth key emission, rocPRIM radix sort,
+// tile ranges) used by both rasterizer variants.  Integer work; results are bit-exact with the
+// reference's CUB pipeline (DSR/DGR rasterizer_impl.cu:70-138, 282-325): any stable LSD radix sort
+// of the same keys gives the same permutation.
+#include "gsr_internal.hpp"
+#include <cstdarg>
+#include <string>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace gsr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+// getHigherMsb (DSR/DGR rasterizer_impl.cu:35-50)
+uint32_t higher_msb(uint32_t n) {
+	uint32_t msb = sizeof(n) * 4;
+	uint32_t step = msb;
+	while (step > 1) {
+		step /= 2;
+		if (n >> msb) msb += step;
+		else msb -= step;
+	}
+	if (n >> msb) msb++;
+	return msb;
+}
+
+size_t scan_temp_bytes(size_t P) {
+	size_t bytes = 0;
+	(void)rocprim::inclusive_scan(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
+	return bytes;
+}
+size_t sort_temp_bytes(size_t R, int end_bit) {
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
+	                                end_bit, 0, false);
+	return bytes;
+}
+
+GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_floats, size_t scan_bytes, size_t* total) {
+	Carver c(buf);
+	GeomState g;
+	g.depths = c.take<float>(P);
+	g.means2D = c.take<float2>(P);
+	g.rect = c.take<uint32_t>(2 * P);
+	g.tiles_touched = c.take<uint32_t>(P);
+	g.point_offsets = c.take<uint32_t>(P);
+	g.clamped = c.take<uint8_t>(P);
+	g.rec = c.take<float4>(P * rec_f4);
+	g.aux = c.take<float>(P * aux_floats);
+	g.acc = c.take<float>(P * acc_floats);
+	g.flags = c.take<int>(4);
+	g.scan_temp = c.take<char>(scan_bytes);
+	g.scan_temp_bytes = scan_bytes;
+	if (total) *total = c.size();
+	return g;
+}
+ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int planes_n, size_t* total) {
+	Carver c(buf);
+	ImageState s;
+	s.ranges = c.take<uint2>(tiles);
+	s.final_T = c.take<float>(HW * planes_T);
+	s.n_contrib = c.take<uint32_t>(HW * planes_n);
+	if (total) *total = c.size();
+	return s;
+}
+BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total) {
+	Carver c(buf);
+	BinningState b;
+	b.keys_unsorted = c.take<uint64_t>(R);
+	b.keys = c.take<uint64_t>(R);
+	b.vals_unsorted = c.take<uint32_t>(R);
+	b.point_list = c.take<uint32_t>(R);
+	b.sort_temp = c.take<char>(sort_bytes);
+	b.sort_temp_bytes = sort_bytes;
+	if (total) *total = c.size();
+	return b;
+}
+
+// duplicateWithKeys (DSR/DGR rasterizer_impl.cu:70-111).  The tile rect was computed once in preprocess
+// and is read back packed, so this kernel is pure integer work: key = tile<<32 | depth bits, value = idx,
+// emission order y outer / x inner.
+__global__ void __launch_bounds__(256) emit_keys_kernel(int P, const uint32_t* __restrict__ rect, const float* __restrict__ depths,
+                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t tiles_x) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	if (tiles_touched[idx] == 0) return;
+	uint32_t off = (idx == 0) ? 0u : offsets[idx - 1];
+	const uint32_t r0 = rect[2 * idx], r1 = rect[2 * idx + 1];
+	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
+	const uint64_t dbits = (uint64_t)__float_as_uint(depths[idx]);
+	for (uint32_t y = y0; y < y1; y++)
+		for (uint32_t x = x0; x < x1; x++) {
+			keys[off] = ((uint64_t)(y * tiles_x + x) << 32) | dbits;
+			vals[off] = (uint32_t)idx;
+			off++;
+		}
+}
+
+// identifyTileRanges (DSR/DGR rasterizer_impl.cu:116-138)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= L) return;
+	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+	if (idx == 0) ranges[currtile].x = 0;
+	else {
+		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+		if (currtile != prevtile) {
+			ranges[prevtile].y = idx;
+			ranges[currtile].x = idx;
+		}
+	}
+	if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// One pinned host word per host thread for the num_rendered readback (the reference does a blocking
+// 4-byte cudaMemcpy on the default stream, rasterizer_impl.cu:286).
+static int* pinned_word() {
+	static thread_local int* w = nullptr;
+	if (!w) {
+		if (hipHostMalloc((void**)&w, 64, hipHostMallocDefault) != hipSuccess) w = nullptr;
+	}
+	return w;
+}
+
+int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom, const ImageState& img,
+                BinningState* out_binning, int debug, hipStream_t stream) {
+	size_t tmp = geom.scan_temp_bytes;
+	GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, geom.tiles_touched, geom.point_offsets, (size_t)P, rocprim::plus<uint32_t>(),
+	                                      stream, false));
+	if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
+	int* host = pinned_word();
+	if (!host) { set_error("hipHostMalloc for the num_rendered readback failed"); return GSR_E_HIP; }
+	GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+	GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+	GSR_HIP_CHECK(hipStreamSynchronize(stream));
+	const int R = host[0];
+	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
+	if (R < 0) { set_error("num_rendered overflowed int32"); return GSR_E_INVALID; }
+
+	const uint32_t tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
+	const int bit = (int)higher_msb(tiles);
+	const size_t sort_bytes = R > 0 ? sort_temp_bytes((size_t)R, 32 + bit) : 0;
+	size_t total = 0;
+	carve_binning(nullptr, (size_t)R, sort_bytes, &total);
+	void* buf = alloc(alloc_user, GSR_BUF_BINNING, total);
+	if (!buf && total > 0) { set_error("binning buffer allocation of %zu bytes failed", total); return GSR_E_ALLOC; }
+	BinningState b = carve_binning(buf, (size_t)R, sort_bytes, nullptr);
+	*out_binning = b;
+
+	GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));
+	if (R > 0) {
+		emit_keys_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.rect, geom.depths, geom.point_offsets, geom.tiles_touched, b.keys_unsorted,
+		                                                      b.vals_unsorted, (uint32_t)tiles_x);
+		GSR_LAUNCH_CHECK(debug, stream);
+		size_t sb = b.sort_temp_bytes;
+		GSR_HIP_CHECK(rocprim::radix_sort_pairs(b.sort_temp, sb, b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list, (size_t)R, 0u,
+		                                        (unsigned)(32 + bit), stream, false));
+		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
+		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.keys, img.ranges);
+		GSR_LAUNCH_CHECK(debug, stream);
+	}
+	return R;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ pts, const float* __restrict__ vm,
+                                                           uint8_t* __restrict__ present) {
+#pragma clang fp contract(off)
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const float x = pts[3 * idx], y = pts[3 * idx + 1], z = pts[3 * idx + 2];
+	const float pz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+	present[idx] = (pz <= 0.2f) ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256) widen_clamped_kernel(int P, const uint8_t* __restrict__ packed, uint8_t* __restrict__ out) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const uint8_t b = packed[idx];
+	out[3 * idx + 0] = b & 1;
+	out[3 * idx + 1] = (b >> 1) & 1;
+	out[3 * idx + 2] = (b >> 2) & 1;
+}
+// Gather `nf` floats starting at float `first` of each record (stride rec_f4*4 floats) into a dense [P, nf] array.
+__global__ void __launch_bounds__(256) gather_rec_kernel(int P, const float* __restrict__ rec, int stride, int first, int nf,
+                                                         float* __restrict__ out) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P * nf) return;
+	const int idx = i / nf, k = i % nf;
+	out[i] = rec[(size_t)idx * stride + first + k];
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" int gsr_version(void) { return 100; }
+
+extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                                void* stream_) {
+	(void)projmatrix;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { set_error("gsr_mark_visible: invalid argument"); return GSR_E_INVALID; }
+	if (P == 0) return 0;
+	mark_visible_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, means3D, viewmatrix, present);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+// Record layouts (must match gsr_gauss.hip / gsr_surfel.hip):
+//   G (16 floats): xy(0,1) conic(2,3,4) opacity(5) rgb(6,7,8) normal(9,10,11) refl(12) invdepth(13) pad pad
+//   S (20 floats): xy(0,1) Tu(2,3,4) Tv(5,6,7) Tw(8,9,10) normal(11,12,13) opacity(14) rgb(15,16,17) refl(18) mask(19)
+extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int width, int height, const void* geom_buffer,
+                               const void* binning_buffer, const void* image_buffer, void* dst, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+	const size_t HW = (size_t)width * height, tiles = (size_t)tiles_x * tiles_y;
+	const int rec_f4 = variant == 0 ? 5 : 4;
+	const int stride = rec_f4 * 4;
+	GeomState g = carve_geom((void*)geom_buffer, P, rec_f4, variant == 0 ? 0 : 6, variant == 0 ? 20 : 16, scan_temp_bytes(P), nullptr);
+	ImageState im = carve_image((void*)image_buffer, HW, tiles, variant == 0 ? 3 : 1, variant == 0 ? 2 : 1, nullptr);
+	BinningState b = carve_binning((void*)binning_buffer, R, 0, nullptr);
+	auto d2d = [&](const void* src, size_t bytes) -> int {
+		if (bytes == 0) return 0;
+		GSR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+		return 0;
+	};
+	auto gather = [&](int first, int nf) -> int {
+		if (P == 0) return 0;
+		gather_rec_kernel<<<(P * nf + 255) / 256, 256, 0, stream>>>(P, (const float*)g.rec, stride, first, nf, (float*)dst);
+		GSR_LAUNCH_CHECK(0, stream);
+		return 0;
+	};
+	std::string n(name);
+	if (n == "depths") return d2d(g.depths, (size_t)P * 4);
+	if (n == "means2D") return d2d(g.means2D, (size_t)P * 8);
+	if (n == "tiles_touched") return d2d(g.tiles_touched, (size_t)P * 4);
+	if (n == "point_offsets") return d2d(g.point_offsets, (size_t)P * 4);
+	if (n == "clamped") {
+		if (P == 0) return 0;
+		widen_clamped_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, g.clamped, (uint8_t*)dst);
+		GSR_LAUNCH_CHECK(0, stream);
+		return 0;
+	}
+	if (n == "rgb") return gather(variant == 0 ? 15 : 6, 3);
+	if (n == "geom4") {  // G: conic.xyz + opacity ; S: normal.xyz + opacity
+		return gather(variant == 0 ? 11 : 2, 4);
+	}
+	if (n == "transMat" && variant == 0) return gather(2, 9);
+	if (n == "cov3D" && variant == 1) return d2d(g.aux, (size_t)P * 6 * 4);
+	if (n == "point_list") return d2d(b.point_list, (size_t)R * 4);
+	if (n == "keys") return d2d(b.keys, (size_t)R * 8);
+	if (n == "ranges") return d2d(im.ranges, tiles * 8);
+	if (n == "final_T") return d2d(im.final_T, HW * 4 * (variant == 0 ? 3 : 1));
+	if (n == "n_contrib") return d2d(im.n_contrib, HW * 4 * (variant == 0 ? 2 : 1));
+	set_error("gsr_debug_fetch: unknown array '%s'", name);
+	return GSR_E_INVALID;
+}

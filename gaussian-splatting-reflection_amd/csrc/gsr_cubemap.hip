@@ -1,0 +1,495 @@
+// Environment cubemap lookup (nearest / bilinear / seamless bilinear) forward + backward, and the fused
+// deferred-reflection pixel pass.  Behaviour follows submodules/cubemapencoder/src/cubemapencoder.cu (CME,
+// LEFT_TOP_AS_ORIGIN branch) and gaussian_renderer/__init__.py:22-35,148,178-179,197-199 +
+// utils/general_utils.py:177-197 of the reference.  One thread per direction / pixel; the cubemap itself
+// (<= 4.7 MB at L = 256) lives in L2 / Infinity Cache, the streaming traffic is the per-pixel planes.
+#include "gsr_internal.hpp"
+
+namespace gsr {
+
+// ----------------------------------------------------------------------------------------------
+// Face / uv selection (CME cubemapencoder.cu:147-187)
+__device__ __forceinline__ void cube_uv(float x, float y, float z, float& u, float& v, int& index) {
+	int max_dim = 0;
+	const float x_ = fabsf(x), y_ = fabsf(y), z_ = fabsf(z);
+	float max_v = x_;
+	if (y_ > max_v) { max_v = y_; max_dim = 1; }
+	if (z_ > max_v) { max_v = z_; max_dim = 2; }
+	if (max_dim == 0) {
+		u = z / x; v = y / x;
+		if (x >= 0.f) { index = 0; u = -u; v = -v; }
+		else { index = 1; u = -u; }
+	} else if (max_dim == 1) {
+		u = x / y; v = z / y;
+		if (y >= 0.f) { index = 2; }
+		else { index = 3; u = -u; v = -v; }
+	} else {
+		u = x / z; v = y / z;
+		if (z >= 0.f) { index = 4; v = -v; }
+		else { index = 5; }
+	}
+}
+
+// Neighbour-face texel across a cube edge (CME cubemapencoder.cu:66-106), as a small table:
+// for (face, flag in {1,2,4,8}) -> new face and how (x', y') derive from (L-1, 0, x, y, L-1-x, L-1-y).
+// Source selectors: 0 -> 0, 1 -> L-1, 2 -> x, 3 -> y, 4 -> L-1-x, 5 -> L-1-y.
+__device__ __forceinline__ void edge_table(int L, int flag, int& face, int& x, int& y) {
+	// packed as face | sx<<4 | sy<<8, index = face*4 + {flag 1:0, 2:1, 4:2, 8:3}
+	const unsigned short tbl[24] = {
+	    4 | (1 << 4) | (3 << 8), 5 | (0 << 4) | (3 << 8), 3 | (1 << 4) | (2 << 8), 2 | (1 << 4) | (2 << 8),   // face 0
+	    5 | (1 << 4) | (3 << 8), 4 | (0 << 4) | (3 << 8), 3 | (0 << 4) | (4 << 8), 2 | (0 << 4) | (4 << 8),   // face 1
+	    1 | (5 << 4) | (1 << 8), 0 | (3 << 4) | (1 << 8), 4 | (2 << 4) | (1 << 8), 5 | (4 << 4) | (1 << 8),   // face 2
+	    1 | (5 << 4) | (0 << 8), 0 | (3 << 4) | (0 << 8), 4 | (2 << 4) | (0 << 8), 5 | (4 << 4) | (0 << 8),   // face 3
+	    1 | (1 << 4) | (3 << 8), 0 | (0 << 4) | (3 << 8), 3 | (2 << 4) | (0 << 8), 2 | (2 << 4) | (0 << 8),   // face 4
+	    0 | (1 << 4) | (3 << 8), 1 | (0 << 4) | (3 << 8), 3 | (4 << 4) | (1 << 8), 2 | (4 << 4) | (1 << 8)};  // face 5
+	const int fi = flag == 1 ? 0 : (flag == 2 ? 1 : (flag == 4 ? 2 : 3));
+	const unsigned e = tbl[face * 4 + fi];
+	const int ix = x, iy = y;
+	auto sel = [&](unsigned s) -> int {
+		switch (s) {
+			case 0: return 0;
+			case 1: return L - 1;
+			case 2: return ix;
+			case 3: return iy;
+			case 4: return L - 1 - ix;
+			default: return L - 1 - iy;
+		}
+	};
+	face = e & 15;
+	x = sel((e >> 4) & 15);
+	y = sel((e >> 8) & 15);
+}
+
+struct Seamless {
+	int f[4], x[4], y[4];  // texel 0: v00, 1: v01 (u neighbour), 2: v10 (v neighbour), 3: v11
+	float kx, ky;
+	int flag;
+	bool is_vertex;
+};
+// Compute_Seamless_Index (CME cubemapencoder.cu:189-263)
+__device__ __forceinline__ void seamless_index(int index, int L, float u, float v, Seamless& s) {
+	float lu = u, lv = -v;
+	lu = (lu * 0.5f + 0.5f) * (float)L;
+	lv = (lv * 0.5f + 0.5f) * (float)L;
+	int ux_0 = (int)floorf(lu - 0.5f), uy_0 = (int)floorf(lv - 0.5f);
+	int ux_1 = ux_0 + 1, uy_1 = uy_0 + 1;
+	float kx = lu - (float)ux_0 - 0.5f;
+	float ky = lv - (float)uy_0 - 0.5f;
+	ux_0 = min(max(ux_0, 0), L - 1); ux_1 = min(max(ux_1, 0), L - 1);
+	uy_0 = min(max(uy_0, 0), L - 1); uy_1 = min(max(uy_1, 0), L - 1);
+	int flag = 0;
+	if (lu < 0.5f) { flag |= 1; kx = 0.5f - lu; }
+	else if (lu >= (float)L - 0.5f) flag |= 2;
+	if (lv < 0.5f) { flag |= 4; ky = 0.5f - lv; }
+	else if (lv >= (float)L - 0.5f) flag |= 8;
+	s.is_vertex = false;
+	for (int i = 0; i < 4; i++) { s.f[i] = index; s.x[i] = ux_0; s.y[i] = uy_0; }
+	if ((flag & 3) && (flag & 12)) {
+		s.is_vertex = true;
+		edge_table(L, flag & 3, s.f[1], s.x[1], s.y[1]);
+		edge_table(L, flag & 12, s.f[2], s.x[2], s.y[2]);
+	} else if (flag & 3) {
+		edge_table(L, flag, s.f[1], s.x[1], s.y[1]);
+		s.y[2] = uy_1;
+		s.y[3] = uy_1;
+		edge_table(L, flag, s.f[3], s.x[3], s.y[3]);
+	} else if (flag & 12) {
+		s.x[1] = ux_1;
+		edge_table(L, flag, s.f[2], s.x[2], s.y[2]);
+		s.x[3] = ux_1;
+		edge_table(L, flag, s.f[3], s.x[3], s.y[3]);
+	} else {
+		s.x[1] = ux_1;
+		s.y[2] = uy_1;
+		s.x[3] = ux_1; s.y[3] = uy_1;
+	}
+	s.kx = kx; s.ky = ky; s.flag = flag;
+}
+
+// Compute_Cubemap_UV_Backward (CME cubemapencoder.cu:265-292); (gu, gv) are modified as there.
+__device__ __forceinline__ void cube_uv_backward(int index, float x, float y, float z, float gu, float gv, float& gx, float& gy, float& gz) {
+	const int face = index / 2;
+	if (face == 0) {
+		if (index == 0) { gu = -gu; gv = -gv; }
+		else { gu = -gu; }
+		gx = -(z * gu + y * gv) / (x * x);
+		gy = 1.f / x * gv;
+		gz = 1.f / x * gu;
+	} else if (face == 1) {
+		if (index != 2) { gu = -gu; gv = -gv; }
+		gx = 1.f / y * gu;
+		gy = -(x * gu + z * gv) / (y * y);
+		gz = 1.f / y * gv;
+	} else {
+		if (index == 4) { gv = -gv; }
+		gx = 1.f / z * gu;
+		gy = 1.f / z * gv;
+		gz = -(x * gu + y * gv) / (z * z);
+	}
+}
+
+__device__ __forceinline__ size_t texel(int f, int c, int y, int x, int C, int L) { return (((size_t)f * C + c) * L + y) * L + x; }
+
+// Plain (non-seamless) footprint shared by the bilinear and nearest modes (CME cubemapencoder.cu:356-378, 409-422)
+struct Plain {
+	int f, ux0, ux1, uy0, uy1;
+	float kx, ky;
+};
+__device__ __forceinline__ void plain_index(float vx, float vy, float vz, int L, Plain& p, bool nearest) {
+	float u, v;
+	cube_uv(vx, vy, vz, u, v, p.f);
+	v = -v;
+	u = (u * 0.5f + 0.5f) * (float)L;
+	v = (v * 0.5f + 0.5f) * (float)L;
+	if (nearest) {
+		p.ux0 = min(max((int)u, 0), L - 1);
+		p.uy0 = min(max((int)v, 0), L - 1);
+		p.ux1 = p.ux0; p.uy1 = p.uy0; p.kx = 0; p.ky = 0;
+		return;
+	}
+	const int ux_0 = (int)floorf(u - 0.5f), uy_0 = (int)floorf(v - 0.5f);
+	p.kx = u - (float)ux_0 - 0.5f;
+	p.ky = v - (float)uy_0 - 0.5f;
+	p.ux0 = min(max(ux_0, 0), L - 1); p.ux1 = min(max(ux_0 + 1, 0), L - 1);
+	p.uy0 = min(max(uy_0, 0), L - 1); p.uy1 = min(max(uy_0 + 1, 0), L - 1);
+}
+
+// ----------------------------------------------------------------------------------------------
+// cubemap_encode_forward (CME cubemapencoder.cu:297-488): outputs [C,B]
+__global__ void __launch_bounds__(256)
+cubemap_fwd_kernel(const float* __restrict__ inputs, const float* __restrict__ cubemap, const float* __restrict__ fail_value,
+                   float* __restrict__ outputs, int interp, int seamless, uint32_t B, int C, int L) {
+	const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= B) return;
+	const float vx = inputs[(size_t)n * 3], vy = inputs[(size_t)n * 3 + 1], vz = inputs[(size_t)n * 3 + 2];
+	if (vx == 0.f && vy == 0.f && vz == 0.f) {
+		for (int c = 0; c < C; c++) outputs[(size_t)c * B + n] = fail_value[c];
+		return;
+	}
+	if (interp == 0 || seamless == 0) {
+		Plain p;
+		plain_index(vx, vy, vz, L, p, interp == 0);
+		for (int c = 0; c < C; c++) {
+			if (interp == 0) {
+				outputs[(size_t)c * B + n] = cubemap[texel(p.f, c, p.uy0, p.ux0, C, L)];
+			} else {
+				const float v00 = cubemap[texel(p.f, c, p.uy0, p.ux0, C, L)], v01 = cubemap[texel(p.f, c, p.uy0, p.ux1, C, L)];
+				const float v10 = cubemap[texel(p.f, c, p.uy1, p.ux0, C, L)], v11 = cubemap[texel(p.f, c, p.uy1, p.ux1, C, L)];
+				outputs[(size_t)c * B + n] = (1 - p.ky) * ((1 - p.kx) * v00 + p.kx * v01) + p.ky * ((1 - p.kx) * v10 + p.kx * v11);
+			}
+		}
+		return;
+	}
+	float u, v;
+	int face;
+	cube_uv(vx, vy, vz, u, v, face);
+	Seamless s;
+	seamless_index(face, L, u, v, s);
+	for (int c = 0; c < C; c++) {
+		const float v00 = cubemap[texel(s.f[0], c, s.y[0], s.x[0], C, L)];
+		const float v01 = cubemap[texel(s.f[1], c, s.y[1], s.x[1], C, L)];
+		const float v10 = cubemap[texel(s.f[2], c, s.y[2], s.x[2], C, L)];
+		const float v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], c, s.y[3], s.x[3], C, L)];
+		outputs[(size_t)c * B + n] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
+	}
+}
+
+// Seamless-bilinear backward for one channel value; returns the (u, v) gradient contribution
+// (CME cubemapencoder.cu:539-581).
+__device__ __forceinline__ void seamless_bwd_channel(const Seamless& s, int c, int C, int L, const float* __restrict__ cubemap,
+                                                     float* __restrict__ grad_cubemap, float g, float& gu, float& gv) {
+	const size_t i00 = texel(s.f[0], c, s.y[0], s.x[0], C, L), i01 = texel(s.f[1], c, s.y[1], s.x[1], C, L);
+	const size_t i10 = texel(s.f[2], c, s.y[2], s.x[2], C, L);
+	const float v00 = cubemap[i00], v01 = cubemap[i01], v10 = cubemap[i10];
+	float v11;
+	if (s.is_vertex) {
+		v11 = (v00 + v01 + v10) / 3.f;
+		const float extra_g = s.ky * s.kx / 3.f;
+		atomicAdd(grad_cubemap + i00, ((1 - s.ky) * (1 - s.kx) + extra_g) * g);
+		atomicAdd(grad_cubemap + i01, ((1 - s.ky) * s.kx + extra_g) * g);
+		atomicAdd(grad_cubemap + i10, ((s.ky * (1 - s.kx)) + extra_g) * g);
+	} else {
+		const size_t i11 = texel(s.f[3], c, s.y[3], s.x[3], C, L);
+		v11 = cubemap[i11];
+		atomicAdd(grad_cubemap + i00, (1 - s.ky) * (1 - s.kx) * g);
+		atomicAdd(grad_cubemap + i01, (1 - s.ky) * s.kx * g);
+		atomicAdd(grad_cubemap + i10, s.ky * (1 - s.kx) * g);
+		atomicAdd(grad_cubemap + i11, s.ky * s.kx * g);
+	}
+	float lg0 = (1 - s.ky) * (v01 - v00) + s.ky * (v11 - v10);
+	float lg1 = (1 - s.kx) * (v10 - v00) + s.kx * (v11 - v01);
+	lg0 *= 0.5f * (float)L * g;
+	lg1 *= 0.5f * (float)L * g;
+	if (s.flag & 1) lg0 = -lg0;
+	if (s.flag & 4) lg1 = -lg1;
+	lg1 = -lg1;
+	gu = lg0;
+	gv = lg1;
+}
+
+// cubemap_encode_backward (CME cubemapencoder.cu:509-779)
+__global__ void __launch_bounds__(256)
+cubemap_bwd_kernel(const float* __restrict__ grad_outputs, const float* __restrict__ inputs, const float* __restrict__ cubemap,
+                   float* __restrict__ grad_cubemap, float* __restrict__ grad_inputs, float* __restrict__ grad_fail, int interp, int seamless,
+                   uint32_t B, int C, int L) {
+	const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+	if (n >= B) return;
+	const float vx = inputs[(size_t)n * 3], vy = inputs[(size_t)n * 3 + 1], vz = inputs[(size_t)n * 3 + 2];
+	float gx = 0.f, gy = 0.f, gz = 0.f;
+	if (vx == 0.f && vy == 0.f && vz == 0.f) {
+		for (int c = 0; c < C; c++) atomicAdd(grad_fail + c, grad_outputs[(size_t)c * B + n]);
+	} else if (interp == 0) {
+		Plain p;
+		plain_index(vx, vy, vz, L, p, true);
+		for (int c = 0; c < C; c++) atomicAdd(grad_cubemap + texel(p.f, c, p.uy0, p.ux0, C, L), grad_outputs[(size_t)c * B + n]);
+	} else if (seamless == 0) {
+		Plain p;
+		plain_index(vx, vy, vz, L, p, false);
+		for (int c = 0; c < C; c++) {
+			const size_t i00 = texel(p.f, c, p.uy0, p.ux0, C, L), i01 = texel(p.f, c, p.uy0, p.ux1, C, L);
+			const size_t i10 = texel(p.f, c, p.uy1, p.ux0, C, L), i11 = texel(p.f, c, p.uy1, p.ux1, C, L);
+			const float v00 = cubemap[i00], v01 = cubemap[i01], v10 = cubemap[i10], v11 = cubemap[i11];
+			const float g = grad_outputs[(size_t)c * B + n];
+			atomicAdd(grad_cubemap + i00, (1 - p.ky) * (1 - p.kx) * g);
+			atomicAdd(grad_cubemap + i01, (1 - p.ky) * p.kx * g);
+			atomicAdd(grad_cubemap + i10, p.ky * (1 - p.kx) * g);
+			atomicAdd(grad_cubemap + i11, p.ky * p.kx * g);
+			float lg0 = (1 - p.ky) * (v01 - v00) + p.ky * (v11 - v10);
+			float lg1 = (1 - p.kx) * (v10 - v00) + p.kx * (v11 - v01);
+			lg0 *= 0.5f * (float)L * g;
+			lg1 *= 0.5f * (float)L * g;
+			lg1 = -lg1;
+			float a, b, cc;
+			cube_uv_backward(p.f, vx, vy, vz, lg0, lg1, a, b, cc);
+			gx += a; gy += b; gz += cc;
+		}
+	} else {
+		float u, v;
+		int face;
+		cube_uv(vx, vy, vz, u, v, face);
+		Seamless s;
+		seamless_index(face, L, u, v, s);
+		for (int c = 0; c < C; c++) {
+			float gu, gv, a, b, cc;
+			seamless_bwd_channel(s, c, C, L, cubemap, grad_cubemap, grad_outputs[(size_t)c * B + n], gu, gv);
+			cube_uv_backward(face, vx, vy, vz, gu, gv, a, b, cc);
+			gx += a; gy += b; gz += cc;
+		}
+	}
+	grad_inputs[(size_t)n * 3] = gx;
+	grad_inputs[(size_t)n * 3 + 1] = gy;
+	grad_inputs[(size_t)n * 3 + 2] = gz;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Fused deferred reflection.  cam block (floats):
+//   [0..8]   world_view_transform[:3,:3], row-major (wvt[j][i] at 3*j+i)
+//   [9..17]  K^-1, row-major
+//   [18..26] Rw = R.T of the camera's stored R (= world-to-camera rotation), row-major
+//   [27..29] T (world-to-camera translation)        [30..32] rays_o = -Rw^T T (camera centre)
+struct ReflPixel {
+	float nwx, nwy, nwz, len;   // un-normalised world normal and its length
+	float nx, ny, nz;           // normalised (/(len + 1e-6))
+	float dx, dy, dz;           // unit view ray
+	float dn;                   // d . n
+	float rx, ry, rz;           // reflected ray
+};
+__device__ __forceinline__ void refl_pixel(const float* __restrict__ cam, float nvx, float nvy, float nvz, int px, int py, ReflPixel& o) {
+	// gaussian_renderer/__init__.py:148 : n_world_j = sum_i n_view_i * wvt[j][i]
+	o.nwx = nvx * cam[0] + nvy * cam[1] + nvz * cam[2];
+	o.nwy = nvx * cam[3] + nvy * cam[4] + nvz * cam[5];
+	o.nwz = nvx * cam[6] + nvy * cam[7] + nvz * cam[8];
+	o.len = sqrtf(o.nwx * o.nwx + o.nwy * o.nwy + o.nwz * o.nwz);
+	const float inv = 1.0f / (o.len + 1e-6f);   // :179
+	o.nx = o.nwx * inv; o.ny = o.nwy * inv; o.nz = o.nwz * inv;
+	// utils/general_utils.py:186-196
+	const float x = (float)px, y = (float)py;
+	const float pcx = cam[9] * x + cam[10] * y + cam[11] - cam[27];
+	const float pcy = cam[12] * x + cam[13] * y + cam[14] - cam[28];
+	const float pcz = cam[15] * x + cam[16] * y + cam[17] - cam[29];
+	float wx = pcx * cam[18] + pcy * cam[21] + pcz * cam[24] - cam[30];
+	float wy = pcx * cam[19] + pcy * cam[22] + pcz * cam[25] - cam[31];
+	float wz = pcx * cam[20] + pcy * cam[23] + pcz * cam[26] - cam[32];
+	const float dl = sqrtf(wx * wx + wy * wy + wz * wz);
+	o.dx = wx / dl; o.dy = wy / dl; o.dz = wz / dl;
+	o.dn = o.dx * o.nx + o.dy * o.ny + o.dz * o.nz;
+	o.rx = o.dx - 2 * o.nx * o.dn;   // gaussian_renderer/__init__.py:22-24
+	o.ry = o.dy - 2 * o.ny * o.dn;
+	o.rz = o.dz - 2 * o.nz * o.dn;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
+                         const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
+                         int H, float* __restrict__ out_final, float* __restrict__ out_refl, float* __restrict__ out_nworld) {
+	const size_t HW = (size_t)W * H;
+	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (pix >= HW) return;
+	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
+	ReflPixel o;
+	refl_pixel(cam, normal_view[pix], normal_view[HW + pix], normal_view[2 * HW + pix], px, py, o);
+	float c[3];
+	if (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f) {
+		c[0] = fail_value[0]; c[1] = fail_value[1]; c[2] = fail_value[2];
+	} else {
+		float u, v;
+		int face;
+		cube_uv(o.rx, o.ry, o.rz, u, v, face);
+		Seamless s;
+		seamless_index(face, L, u, v, s);
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) {
+			const float v00 = cubemap[texel(s.f[0], ch, s.y[0], s.x[0], 3, L)];
+			const float v01 = cubemap[texel(s.f[1], ch, s.y[1], s.x[1], 3, L)];
+			const float v10 = cubemap[texel(s.f[2], ch, s.y[2], s.x[2], 3, L)];
+			const float v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], ch, s.y[3], s.x[3], 3, L)];
+			c[ch] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
+		}
+	}
+	const float sv = strength[pix];
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+		const float rc = sigmoidf_(c[ch]);
+		out_refl[ch * HW + pix] = rc;
+		out_final[ch * HW + pix] = (1 - sv) * base[ch * HW + pix] + sv * rc;
+	}
+	out_nworld[pix] = o.nx;
+	out_nworld[HW + pix] = o.ny;
+	out_nworld[2 * HW + pix] = o.nz;
+}
+
+__global__ void __launch_bounds__(256)
+deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
+                         const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
+                         int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color, const float* __restrict__ g_nworld,
+                         float* __restrict__ g_normal_view, float* __restrict__ g_base, float* __restrict__ g_strength,
+                         float* __restrict__ g_cubemap, float* __restrict__ g_fail) {
+	const size_t HW = (size_t)W * H;
+	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (pix >= HW) return;
+	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
+	ReflPixel o;
+	refl_pixel(cam, normal_view[pix], normal_view[HW + pix], normal_view[2 * HW + pix], px, py, o);
+	const bool fail = (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f);
+	Seamless s;
+	int face = 0;
+	float c[3];
+	if (fail) {
+		c[0] = fail_value[0]; c[1] = fail_value[1]; c[2] = fail_value[2];
+	} else {
+		float u, v;
+		cube_uv(o.rx, o.ry, o.rz, u, v, face);
+		seamless_index(face, L, u, v, s);
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) {
+			const float v00 = cubemap[texel(s.f[0], ch, s.y[0], s.x[0], 3, L)];
+			const float v01 = cubemap[texel(s.f[1], ch, s.y[1], s.x[1], 3, L)];
+			const float v10 = cubemap[texel(s.f[2], ch, s.y[2], s.x[2], 3, L)];
+			const float v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], ch, s.y[3], s.x[3], 3, L)];
+			c[ch] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
+		}
+	}
+	const float sv = strength[pix];
+	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+		const float rc = sigmoidf_(c[ch]);
+		const float gf = g_final[ch * HW + pix];
+		const float b = base[ch * HW + pix];
+		g_base[ch * HW + pix] = (1 - sv) * gf;
+		gs += gf * (rc - b);
+		float gc = sv * gf;
+		if (g_refl_color) gc += g_refl_color[ch * HW + pix];
+		const float graw = gc * rc * (1 - rc);   // sigmoid'
+		if (fail) {
+			atomicAdd(g_fail + ch, graw);
+		} else {
+			float gu, gv, a, bb, cc;
+			seamless_bwd_channel(s, ch, 3, L, cubemap, g_cubemap, graw, gu, gv);
+			cube_uv_backward(face, o.rx, o.ry, o.rz, gu, gv, a, bb, cc);
+			grx += a; gry += bb; grz += cc;
+		}
+	}
+	g_strength[pix] = gs;
+	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
+	const float grn = grx * o.nx + gry * o.ny + grz * o.nz;
+	float gnx = -2.f * (o.dn * grx + grn * o.dx);
+	float gny = -2.f * (o.dn * gry + grn * o.dy);
+	float gnz = -2.f * (o.dn * grz + grn * o.dz);
+	if (g_nworld) { gnx += g_nworld[pix]; gny += g_nworld[HW + pix]; gnz += g_nworld[2 * HW + pix]; }
+	// n = nw / (|nw| + eps): g_nw = g_n / (len+eps) - nw (nw.g_n) / (len (len+eps)^2)   (0 subgradient at len = 0)
+	const float inv = 1.0f / (o.len + 1e-6f);
+	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
+	if (o.len > 0.f) {
+		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv / o.len;
+		gwx -= o.nwx * k; gwy -= o.nwy * k; gwz -= o.nwz * k;
+	}
+	g_normal_view[pix] = gwx * cam[0] + gwy * cam[3] + gwz * cam[6];
+	g_normal_view[HW + pix] = gwx * cam[1] + gwy * cam[4] + gwz * cam[7];
+	g_normal_view[2 * HW + pix] = gwx * cam[2] + gwy * cam[5] + gwz * cam[8];
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" int gsr_cubemap_forward(const float* inputs, const float* cubemap, const float* fail_value, float* outputs, uint32_t interp,
+                                   uint32_t seamless, uint32_t B, uint32_t C, uint32_t L, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (B == 0) return 0;
+	if (!inputs || !cubemap || !fail_value || !outputs || C == 0 || L == 0) { set_error("gsr_cubemap_forward: invalid argument"); return GSR_E_INVALID; }
+	cubemap_fwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(inputs, cubemap, fail_value, outputs, (int)interp, (int)seamless, B, (int)C, (int)L);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_cubemap_backward(const float* grad_outputs, const float* inputs, const float* cubemap, float* grad_cubemap,
+                                    float* grad_inputs, float* grad_fail, uint32_t interp, uint32_t seamless, uint32_t B, uint32_t C, uint32_t L,
+                                    void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (B == 0) return 0;
+	if (!grad_outputs || !inputs || !cubemap || !grad_cubemap || !grad_inputs || !grad_fail || C == 0 || L == 0) {
+		set_error("gsr_cubemap_backward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	cubemap_bwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(grad_outputs, inputs, cubemap, grad_cubemap, grad_inputs, grad_fail, (int)interp,
+	                                                        (int)seamless, B, (int)C, (int)L);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                               const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                               float* out_final, float* out_refl_color, float* out_normal_world, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !out_final ||
+	    !out_refl_color || !out_normal_world || L == 0) {
+		set_error("gsr_deferred_reflection_forward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	deferred_refl_fwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+	                                                                         (int)L, width, height, out_final, out_refl_color, out_normal_world);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                                const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                                const float* g_final, const float* g_refl_color, const float* g_normal_world,
+                                                float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
+                                                void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
+	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || L == 0) {
+		set_error("gsr_deferred_reflection_backward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	deferred_refl_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+	                                                                         (int)L, width, height, g_final, g_refl_color, g_normal_world,
+	                                                                         g_normal_view, g_base, g_strength, g_cubemap, g_fail);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}

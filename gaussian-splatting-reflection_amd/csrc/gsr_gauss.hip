@@ -1,0 +1,718 @@
+// Variant G — 3D Gaussians (EWA projection, anti-aliasing, inverse depth, normal / reflection-strength
+// channels).  MI355X-native restatement of the behaviour of submodules/diff-gaussian-rasterization
+// (DGR cuda_rasterizer/forward.cu, backward.cu, rasterizer_impl.cu); design notes in DESIGN.md.
+//
+// Data layout: preprocess writes one 64-byte render record per Gaussian
+//   f4[0] = (x, y, conic.x, conic.y)  f4[1] = (conic.z, opacity, r, g)
+//   f4[2] = (b, nx, ny, nz)           f4[3] = (refl, 1/depth, -, -)
+// which the tile kernels gather with four lanes per record (64 contiguous bytes) into LDS.
+// A 16x16 tile is one 256-thread workgroup = 4 waves, each wave owning an 8x8 pixel quadrant so that
+// wave-uniform skips ("no lane of this wave touches Gaussian j") fire as often as possible.
+#include "gsr_internal.hpp"
+#include "gsr_math.hpp"
+
+namespace gsr {
+
+#define G_REC_F4 4
+#define G_ACC_F 16
+// accumulator slots (floats) of the backward tile kernel / per-Gaussian backward
+#define GA_COLOR 0
+#define GA_NORMAL 3
+#define GA_REFL 6
+#define GA_INVD 7
+#define GA_MEAN2D 8
+#define GA_MEAN2DP 10
+#define GA_CONIC 12
+#define GA_OPAC 15
+
+struct GaussCam {
+	const float* view;
+	const float* proj;
+	const float* campos;
+	int W, H;
+	float tan_fovx, tan_fovy, focal_x, focal_y;
+};
+
+// computeCov3D (DGR forward.cu:114-148): quaternion used as given (not normalised).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scale, float mod, const float* __restrict__ rot, float* cov3D) {
+#pragma clang fp contract(off)
+	M3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+	S.m[0][0] = mod * scale[0];
+	S.m[1][1] = mod * scale[1];
+	S.m[2][2] = mod * scale[2];
+	const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+	M3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y), 2.f * (x * y + r * z),
+	               1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x), 2.f * (x * z - r * y), 2.f * (y * z + r * x),
+	               1.f - 2.f * (x * x + y * y));
+	M3 Mm = m3_mul(S, R);
+	M3 Sigma = m3_mul(m3_T(Mm), Mm);
+	cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+	cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+// Shared by forward and backward: view-space point with the 1.3*tanfov clamp, J, W, T = W*J (DGR forward.cu:80-99).
+struct Cov2DCtx {
+	float tx, ty, tz, txtz, tytz, limx, limy;
+	M3 T, Wm;
+};
+__device__ __forceinline__ Cov2DCtx cov2d_ctx(float mx, float my, float mz, const GaussCam& c) {
+#pragma clang fp contract(off)
+	const float* vm = c.view;
+	Cov2DCtx k;
+	float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+	float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+	const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+	k.limx = 1.3f * c.tan_fovx;
+	k.limy = 1.3f * c.tan_fovy;
+	k.txtz = tx / tz;
+	k.tytz = ty / tz;
+	tx = fminf(k.limx, fmaxf(-k.limx, k.txtz)) * tz;
+	ty = fminf(k.limy, fmaxf(-k.limy, k.tytz)) * tz;
+	k.tx = tx; k.ty = ty; k.tz = tz;
+	M3 J = m3_make(c.focal_x / tz, 0.0f, -(c.focal_x * tx) / (tz * tz), 0.0f, c.focal_y / tz, -(c.focal_y * ty) / (tz * tz), 0, 0, 0);
+	k.Wm = m3_make(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+	k.T = m3_mul(k.Wm, J);
+	return k;
+}
+
+// preprocessCUDA forward (DGR forward.cu:151-269).  FMA contraction off: radii, tile rects and sort keys
+// must match the oracle bit for bit.
+__global__ void __launch_bounds__(256)
+gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                        const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                        const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp, const float* __restrict__ normals,
+                        const float* __restrict__ refl, GaussCam cam, int* __restrict__ radii, GeomState g, int gx, int gy, int prefiltered,
+                        int antialiasing) {
+#pragma clang fp contract(off)
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	radii[idx] = 0;
+	g.tiles_touched[idx] = 0;
+	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
+	const float* vm = cam.view;
+	const float* pm = cam.proj;
+	const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+	if (pvz <= 0.2f) {  // in_frustum (DGR auxiliary.h:151-176)
+		if (prefiltered) g.flags[0] = 1;
+		return;
+	}
+	const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+	const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+	const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+	const float p_w = 1.0f / (hw + 0.0000001f);
+	const float projx = hx * p_w, projy = hy * p_w;
+
+	float cov3D[6];
+	if (cov3D_precomp != nullptr) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
+	} else {
+		cov3d_from_scale_rot(scales + 3 * idx, scale_modifier, rotations + 4 * idx, cov3D);
+#pragma unroll
+		for (int i = 0; i < 6; i++) g.aux[6 * idx + i] = cov3D[i];
+	}
+	const Cov2DCtx k = cov2d_ctx(mx, my, mz, cam);
+	const M3 Vrk = m3_make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+	const M3 cov = m3_mul(m3_mul(m3_T(k.T), m3_T(Vrk)), k.T);
+	float cx = cov.m[0][0], cy = cov.m[0][1], cz = cov.m[1][1];
+	const float h_var = 0.3f;
+	const float det_cov = cx * cz - cy * cy;
+	cx += h_var;
+	cz += h_var;
+	const float det = cx * cz - cy * cy;
+	float h_convolution_scaling = 1.0f;
+	if (antialiasing) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det));
+	if (det == 0.0f) return;
+	const float det_inv = 1.f / det;
+	const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+	const float mid = 0.5f * (cx + cz);
+	const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+	const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+	// ndc2Pix (DGR auxiliary.h:40-43) is written in double there
+	const float pix_x = (float)((((double)projx + 1.0) * cam.W - 1.0) * 0.5);
+	const float pix_y = (float)((((double)projy + 1.0) * cam.H - 1.0) * 0.5);
+	uint32_t x0, y0, x1, y1;
+	get_rect(pix_x, pix_y, f2i(my_radius), gx, gy, x0, y0, x1, y1);
+	if ((x1 - x0) * (y1 - y0) == 0) return;
+
+	float cr, cg, cb;
+	if (colors_precomp == nullptr) {
+		const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+		ShRow s;
+		load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+		const F3 c = sh_eval(D, s, dx / len, dy / len, dz / len);
+		g.clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
+		cr = fmaxf(c.x, 0.0f); cg = fmaxf(c.y, 0.0f); cb = fmaxf(c.z, 0.0f);
+	} else {
+		cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+	}
+	g.depths[idx] = pvz;
+	radii[idx] = f2i(my_radius);
+	g.means2D[idx] = make_float2(pix_x, pix_y);
+	g.rect[2 * idx] = x0 | (y0 << 16);
+	g.rect[2 * idx + 1] = x1 | (y1 << 16);
+	float4* rec = g.rec + (size_t)idx * G_REC_F4;
+	rec[0] = make_float4(pix_x, pix_y, conx, cony);
+	rec[1] = make_float4(conz, opacities[idx] * h_convolution_scaling, cr, cg);
+	rec[2] = make_float4(cb, normals[3 * idx], normals[3 * idx + 1], normals[3 * idx + 2]);
+	rec[3] = make_float4(refl[idx], 1.0f / pvz, 0.f, 0.f);
+	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
+}
+
+// Per (pixel, Gaussian) falloff shared VERBATIM by the forward and backward tile kernels: the backward
+// recovers T by dividing by (1 - alpha), so alpha must be the same bits in both.  Explicit fmaf + no
+// further contraction makes the instruction sequence independent of the surrounding code.
+__device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, float pixx, float pixy, float& dx, float& dy, float& G,
+                                           float& alpha) {
+#pragma clang fp contract(off)
+	dx = r0.x - pixx;
+	dy = r0.y - pixy;
+	const float q = fmaf(r0.z * dx, dx, (conz * dy) * dy);
+	const float power = fmaf(-0.5f, q, -((r0.w * dx) * dy));
+	if (power > 0.0f) return false;
+	G = __expf(power);
+	alpha = fminf(0.99f, opac * G);
+	return !(alpha < 1.0f / 255.0f);
+}
+
+// renderCUDA forward (DGR forward.cu:274-411)
+template <bool INVDEPTH>
+__global__ void __launch_bounds__(256)
+gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                        const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
+                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_normal,
+                        float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
+	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+	if (tile >= (uint32_t)ntiles) return;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixx = (float)px, pixy = (float)py;
+	const uint2 range = ranges[tile];
+	const int count = (int)(range.y - range.x);
+
+	__shared__ float4 s_rec[256 * G_REC_F4];
+	__shared__ int s_done[4];
+
+	bool done = !inside;
+	float T = 1.0f;
+	uint32_t last_contributor = 0;
+	float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, RS = 0, ID = 0;
+
+	for (int base = 0; base < count; base += 256) {
+		// block-wide "everyone done" vote (reference: __syncthreads_count(done) == BLOCK_SIZE)
+		const bool wave_done = __ballot(!done) == 0ull;
+		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+		__syncthreads();
+		if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == 4) break;
+		// cooperative gather: 4 lanes per 64-byte record
+		const int nb = min(256, count - base);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int i = k * 64 + (tid >> 2);
+			if (i < nb) {
+				const uint32_t id = point_list[range.x + base + i];
+				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
+			}
+		}
+		__syncthreads();
+		if (!wave_done) {
+			for (int j = 0; j < nb; j++) {
+				const float4 r0 = s_rec[j * G_REC_F4 + 0];
+				const float4 r1 = s_rec[j * G_REC_F4 + 1];
+				float dx, dy, G, alpha;
+				bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+				float test_T = 0.f;
+				if (ok) {
+					test_T = T * (1 - alpha);
+					if (test_T < 0.0001f) {
+						done = true;
+						ok = false;
+					}
+				}
+				if (__ballot(ok) != 0ull) {
+					const float4 r2 = s_rec[j * G_REC_F4 + 2];
+					const float4 r3 = s_rec[j * G_REC_F4 + 3];
+					if (ok) {
+						const float w = alpha * T;
+						C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
+						N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
+						RS = fmaf(r3.x, w, RS);
+						if (INVDEPTH) ID = fmaf(r3.y, w, ID);
+						T = test_T;
+						last_contributor = (uint32_t)(base + j + 1);
+					}
+				} else if (__ballot(!done) == 0ull) {
+					break;
+				}
+			}
+		}
+	}
+	if (inside) {
+		const size_t HW = (size_t)H * W;
+		const size_t pix = (size_t)W * py + px;
+		final_T[pix] = T;
+		n_contrib[pix] = last_contributor;
+		out_color[pix] = C0 + T * bg[0];
+		out_color[HW + pix] = C1 + T * bg[1];
+		out_color[2 * HW + pix] = C2 + T * bg[2];
+		out_normal[pix] = N0;
+		out_normal[HW + pix] = N1;
+		out_normal[2 * HW + pix] = N2;
+		out_refl[pix] = RS;
+		if (INVDEPTH) out_invdepth[pix] = ID;
+	}
+}
+
+// renderCUDA backward (DGR backward.cu:452-690).  The reference issues 16 float atomicAdds per
+// contributing (pixel, Gaussian) pair; here each wave reduces its 64 pixels with DPP adds, the four
+// waves meet in LDS, and one 64-byte row per (tile, Gaussian) goes out as four 16-byte-per-lane atomic
+// segments into a private [P][16] accumulator that the per-Gaussian kernel then consumes.
+#define G_BWD_BATCH 64
+template <bool INVDEPTH>
+__global__ void __launch_bounds__(256)
+gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                        const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_Ts,
+                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dnormal_map,
+                        const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_invdepths, float* __restrict__ acc) {
+	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+	if (tile >= (uint32_t)ntiles) return;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixx = (float)px, pixy = (float)py;
+	const uint2 range = ranges[tile];
+	const int count = (int)(range.y - range.x);
+	const size_t HW = (size_t)H * W;
+	const size_t pix = (size_t)W * py + px;
+
+	__shared__ float4 s_rec[G_BWD_BATCH * G_REC_F4];
+	__shared__ uint32_t s_id[G_BWD_BATCH];
+	__shared__ float4 s_slab[4][G_BWD_BATCH][G_ACC_F / 4];
+	__shared__ unsigned long long s_touched[4];
+
+	const float T_final = inside ? final_Ts[pix] : 0.f;
+	float T = T_final;
+	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+	float acc_c0 = 0, acc_c1 = 0, acc_c2 = 0, acc_n0 = 0, acc_n1 = 0, acc_n2 = 0, acc_r = 0, acc_i = 0;
+	float dp0 = 0, dp1 = 0, dp2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, dr = 0, di = 0;
+	if (inside) {
+		dp0 = dL_dpixels[pix]; dp1 = dL_dpixels[HW + pix]; dp2 = dL_dpixels[2 * HW + pix];
+		dn0 = dL_dnormal_map[pix]; dn1 = dL_dnormal_map[HW + pix]; dn2 = dL_dnormal_map[2 * HW + pix];
+		dr = dL_drefl_map[pix];
+		if (INVDEPTH) di = dL_invdepths[pix];
+	}
+	float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, ln0 = 0, ln1 = 0, ln2 = 0, lr = 0, li = 0;
+	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+	const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+
+	for (int base = 0; base < count; base += G_BWD_BATCH) {
+		const int nb = min(G_BWD_BATCH, count - base);
+		__syncthreads();  // previous batch fully flushed before its LDS is overwritten
+		{
+			const int i = tid >> 2;
+			if (i < nb) {
+				const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
+				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
+				if ((tid & 3) == 0) s_id[i] = id;
+			}
+		}
+		__syncthreads();
+		unsigned long long touched = 0ull;
+		for (int j = 0; j < nb; j++) {
+			const int contributor = count - 1 - (base + j);  // index in the front-to-back list
+			const float4 r0 = s_rec[j * G_REC_F4 + 0];
+			const float4 r1 = s_rec[j * G_REC_F4 + 1];
+			float dx, dy, G, alpha;
+			const bool ok = inside && contributor < last_contributor && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+			if (__ballot(ok) == 0ull) continue;
+			const float4 r2 = s_rec[j * G_REC_F4 + 2];
+			const float4 r3 = s_rec[j * G_REC_F4 + 3];
+			float v[G_ACC_F];
+#pragma unroll
+			for (int q = 0; q < G_ACC_F; q++) v[q] = 0.f;
+			if (ok) {
+				T = T / (1.f - alpha);
+				const float dchannel_dcolor = alpha * T;
+				float dL_dalpha = 0.0f, dL_dalpha_means2d = 0.0f;
+				// colour channels; dL_dalpha_means2d is the running sum INSIDE the loop (DGR backward.cu:613-614)
+				acc_c0 = last_alpha * lc0 + (1.f - last_alpha) * acc_c0; lc0 = r1.z;
+				dL_dalpha += (r1.z - acc_c0) * dp0; dL_dalpha_means2d += dL_dalpha;
+				acc_c1 = last_alpha * lc1 + (1.f - last_alpha) * acc_c1; lc1 = r1.w;
+				dL_dalpha += (r1.w - acc_c1) * dp1; dL_dalpha_means2d += dL_dalpha;
+				acc_c2 = last_alpha * lc2 + (1.f - last_alpha) * acc_c2; lc2 = r2.x;
+				dL_dalpha += (r2.x - acc_c2) * dp2; dL_dalpha_means2d += dL_dalpha;
+				v[GA_COLOR + 0] = dchannel_dcolor * dp0;
+				v[GA_COLOR + 1] = dchannel_dcolor * dp1;
+				v[GA_COLOR + 2] = dchannel_dcolor * dp2;
+				acc_n0 = last_alpha * ln0 + (1.f - last_alpha) * acc_n0; ln0 = r2.y; dL_dalpha += (r2.y - acc_n0) * dn0;
+				acc_n1 = last_alpha * ln1 + (1.f - last_alpha) * acc_n1; ln1 = r2.z; dL_dalpha += (r2.z - acc_n1) * dn1;
+				acc_n2 = last_alpha * ln2 + (1.f - last_alpha) * acc_n2; ln2 = r2.w; dL_dalpha += (r2.w - acc_n2) * dn2;
+				v[GA_NORMAL + 0] = dchannel_dcolor * dn0;
+				v[GA_NORMAL + 1] = dchannel_dcolor * dn1;
+				v[GA_NORMAL + 2] = dchannel_dcolor * dn2;
+				acc_r = last_alpha * lr + (1.f - last_alpha) * acc_r; lr = r3.x;
+				dL_dalpha += (r3.x - acc_r) * dr;
+				v[GA_REFL] = dchannel_dcolor * dr;
+				if (INVDEPTH) {
+					acc_i = last_alpha * li + (1.f - last_alpha) * acc_i; li = r3.y;
+					dL_dalpha += (r3.y - acc_i) * di;
+					v[GA_INVD] = dchannel_dcolor * di;
+				}
+				dL_dalpha *= T;
+				dL_dalpha_means2d *= T;
+				last_alpha = alpha;
+				const float bgterm = (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+				dL_dalpha += bgterm;
+				dL_dalpha_means2d += bgterm;
+				const float dL_dG = r1.y * dL_dalpha;
+				const float dL_dG_means2d = r1.y * dL_dalpha_means2d;
+				const float gdx = G * dx, gdy = G * dy;
+				const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+				const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+				v[GA_MEAN2D + 0] = dL_dG * dG_ddelx * ddelx_dx;
+				v[GA_MEAN2D + 1] = dL_dG * dG_ddely * ddely_dy;
+				v[GA_MEAN2DP + 0] = dL_dG_means2d * dG_ddelx * ddelx_dx;
+				v[GA_MEAN2DP + 1] = dL_dG_means2d * dG_ddely * ddely_dy;
+				v[GA_CONIC + 0] = -0.5f * gdx * dx * dL_dG;
+				v[GA_CONIC + 1] = -0.5f * gdx * dy * dL_dG;
+				v[GA_CONIC + 2] = -0.5f * gdy * dy * dL_dG;
+				v[GA_OPAC] = G * dL_dalpha;
+			}
+			wave_sum8(v);
+			wave_sum8(v + 8);
+			if (lane == 63) {
+				s_slab[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
+				s_slab[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
+				s_slab[wave][j][2] = make_float4(v[8], v[9], v[10], v[11]);
+				s_slab[wave][j][3] = make_float4(v[12], v[13], v[14], v[15]);
+			}
+			touched |= 1ull << j;
+		}
+		if (lane == 0) s_touched[wave] = touched;
+		__syncthreads();
+		{
+			const int i = tid >> 2, q = tid & 3;
+			if (i < nb) {
+				float4 s = make_float4(0, 0, 0, 0);
+				bool any = false;
+#pragma unroll
+				for (int w = 0; w < 4; w++) {
+					if ((s_touched[w] >> i) & 1ull) {
+						const float4 t = s_slab[w][i][q];
+						s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+						any = true;
+					}
+				}
+				if (any) {
+					float* dst = acc + (size_t)s_id[i] * G_ACC_F + q * 4;
+					atomicAdd(dst + 0, s.x);
+					atomicAdd(dst + 1, s.y);
+					atomicAdd(dst + 2, s.z);
+					atomicAdd(dst + 3, s.w);
+				}
+			}
+		}
+	}
+}
+
+// computeCov2DCUDA + preprocessCUDA backward + computeCov3D backward fused into one per-Gaussian pass
+// (DGR backward.cu:147-326, 330-393, 399-449).  Every output element is written (zeros for culled
+// Gaussians), so the caller does not need the reference's 11 zero-filled tensors.
+__global__ void __launch_bounds__(256)
+gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
+                            const uint8_t* __restrict__ clamped, const float* __restrict__ opacities, const float* __restrict__ scales,
+                            const float* __restrict__ rotations, float scale_modifier, const float* __restrict__ cov3Ds, GaussCam cam,
+                            const float* __restrict__ acc, int has_invdepth, int antialiasing, float* __restrict__ dL_dmean2D,
+                            float* __restrict__ dL_dmean2D_pixels, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                            float* __restrict__ dL_dcolor, float* __restrict__ dL_dnormals, float* __restrict__ dL_drefl,
+                            float* __restrict__ dL_dinvdepth, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+                            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const float4* a4 = reinterpret_cast<const float4*>(acc + (size_t)idx * G_ACC_F);
+	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
+	// pass-through outputs of the tile kernel
+	dL_dcolor[3 * idx] = a0.x; dL_dcolor[3 * idx + 1] = a0.y; dL_dcolor[3 * idx + 2] = a0.z;
+	dL_dnormals[3 * idx] = a0.w; dL_dnormals[3 * idx + 1] = a1.x; dL_dnormals[3 * idx + 2] = a1.y;
+	dL_drefl[idx] = a1.z;
+	if (has_invdepth) dL_dinvdepth[idx] = a1.w;
+	dL_dmean2D[3 * idx] = a2.x; dL_dmean2D[3 * idx + 1] = a2.y; dL_dmean2D[3 * idx + 2] = 0.f;
+	dL_dmean2D_pixels[3 * idx] = a2.z; dL_dmean2D_pixels[3 * idx + 1] = a2.w; dL_dmean2D_pixels[3 * idx + 2] = 0.f;
+	reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
+	float dL_dopac = a3.w;
+
+	float dmean[3] = {0.f, 0.f, 0.f};
+	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float dscale[3] = {0.f, 0.f, 0.f};
+	float drot[4] = {0.f, 0.f, 0.f, 0.f};
+	const bool visible = radii[idx] > 0;
+	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
+	if (visible) {
+		// ---- computeCov2DCUDA
+		const float* cov3D = cov3Ds + 6 * idx;
+		const float c3[6] = {cov3D[0], cov3D[1], cov3D[2], cov3D[3], cov3D[4], cov3D[5]};
+		const Cov2DCtx k = cov2d_ctx(mx, my, mz, cam);
+		const float x_grad_mul = (k.txtz < -k.limx || k.txtz > k.limx) ? 0.f : 1.f;
+		const float y_grad_mul = (k.tytz < -k.limy || k.tytz > k.limy) ? 0.f : 1.f;
+		const M3 Vrk = m3_make(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+		const M3& T = k.T;
+		const M3& Wm = k.Wm;
+		const M3 cov2D = m3_mul(m3_mul(m3_T(T), m3_T(Vrk)), T);
+		float c_xx = cov2D.m[0][0], c_xy = cov2D.m[0][1], c_yy = cov2D.m[1][1];
+		const float h_var = 0.3f;
+		float d_inside_root = 0.f;
+		if (antialiasing) {
+			const float det_cov = c_xx * c_yy - c_xy * c_xy;
+			c_xx += h_var;
+			c_yy += h_var;
+			const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
+			const float h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+			const float dL_dopacity_v = dL_dopac;
+			const float d_h_convolution_scaling = dL_dopacity_v * opacities[idx];
+			dL_dopac = dL_dopacity_v * h_convolution_scaling;
+			d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_h_convolution_scaling / (2 * h_convolution_scaling);
+		} else {
+			c_xx += h_var;
+			c_yy += h_var;
+		}
+		float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
+		if (antialiasing) {
+			const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
+			const float dn = (w * w + w * (x + y) + x * y - z * z);
+			const float denom_f = d_inside_root / (dn * dn);
+			dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
+			dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
+			dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
+		}
+		const float dcx = a3.x, dcy = a3.y, dcz = a3.z;  // dL_dconic slots x, y, w
+		const float denom = c_xx * c_yy - c_xy * c_xy;
+		const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+		if (denom2inv != 0) {
+			dL_dc_xx += denom2inv * (-c_yy * c_yy * dcx + 2 * c_xy * c_yy * dcy + (denom - c_xx * c_yy) * dcz);
+			dL_dc_yy += denom2inv * (-c_xx * c_xx * dcz + 2 * c_xx * c_xy * dcy + (denom - c_xx * c_yy) * dcx);
+			dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dcx - (denom + 2 * c_xy * c_xy) * dcy + c_xx * c_xy * dcz);
+			dcov[0] = (T.m[0][0] * T.m[0][0] * dL_dc_xx + T.m[0][0] * T.m[1][0] * dL_dc_xy + T.m[1][0] * T.m[1][0] * dL_dc_yy);
+			dcov[3] = (T.m[0][1] * T.m[0][1] * dL_dc_xx + T.m[0][1] * T.m[1][1] * dL_dc_xy + T.m[1][1] * T.m[1][1] * dL_dc_yy);
+			dcov[5] = (T.m[0][2] * T.m[0][2] * dL_dc_xx + T.m[0][2] * T.m[1][2] * dL_dc_xy + T.m[1][2] * T.m[1][2] * dL_dc_yy);
+			dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_dc_xx + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_dc_xy + 2 * T.m[1][0] * T.m[1][1] * dL_dc_yy;
+			dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_dc_xx + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_dc_xy + 2 * T.m[1][0] * T.m[1][2] * dL_dc_yy;
+			dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_dc_xx + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_dc_xy + 2 * T.m[1][1] * T.m[1][2] * dL_dc_yy;
+		}
+		const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_dc_xx +
+		                      (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc_xy;
+		const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_dc_xx +
+		                      (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc_xy;
+		const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_dc_xx +
+		                      (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc_xy;
+		const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc_yy +
+		                      (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_dc_xy;
+		const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc_yy +
+		                      (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_dc_xy;
+		const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc_yy +
+		                      (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_dc_xy;
+		const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+		const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+		const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+		const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+		const float tz = 1.f / k.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+		const float h_x = cam.focal_x, h_y = cam.focal_y;
+		const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+		const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+		float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * k.tx) * tz3 * dL_dJ02 + (2 * h_y * k.ty) * tz3 * dL_dJ12;
+		if (has_invdepth) dL_dtz -= a1.w / (k.tz * k.tz);
+		const float* vm = cam.view;
+		dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;   // assignment (DGR backward.cu:325)
+		dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+		dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+		// ---- preprocessCUDA backward: projection Jacobian of the 2-D mean
+		const float* proj = cam.proj;
+		const float m_hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+		const float m_w = 1.0f / (m_hw + 0.0000001f);
+		const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+		const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+		const float g2x = a2.x, g2y = a2.y;
+		dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+		dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+		dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+		// ---- computeCov3D backward (unnormalised quaternion, DGR backward.cu:392)
+		if (scales != nullptr) {
+			const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+			const M3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y), 2.f * (x * y + r * z),
+			                     1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x), 2.f * (x * z - r * y), 2.f * (y * z + r * x),
+			                     1.f - 2.f * (x * x + y * y));
+			const float sx = scale_modifier * scales[3 * idx], sy = scale_modifier * scales[3 * idx + 1], sz = scale_modifier * scales[3 * idx + 2];
+			M3 S = m3_make(sx, 0, 0, 0, sy, 0, 0, 0, sz);
+			M3 Mm = m3_mul(S, R);
+			M3 dSigma = m3_make(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+#pragma unroll
+				for (int n = 0; n < 3; n++) Mm.m[c][n] *= 2.0f;
+			const M3 dL_dM = m3_mul(Mm, dSigma);
+			const M3 Rt = m3_T(R);
+			M3 dMt = m3_T(dL_dM);
+			dscale[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+			dscale[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+			dscale[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+			for (int n = 0; n < 3; n++) { dMt.m[0][n] *= sx; dMt.m[1][n] *= sy; dMt.m[2][n] *= sz; }
+			drot[0] = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+			drot[1] = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+			drot[2] = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+			drot[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+		}
+	}
+	dL_dopacity[idx] = dL_dopac;
+	// ---- SH backward (also writes the dL_dsh row, zeros when not visible)
+	if (shs != nullptr) {
+		if (visible) {
+			ShRow s;
+			load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+			const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+			const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(a0.x, a0.y, a0.z), dL_dsh);
+			dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+		} else {
+			float* out = dL_dsh + (size_t)idx * M * 3;
+			for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+		}
+	}
+	dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+	for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
+	dL_dscale[3 * idx] = dscale[0]; dL_dscale[3 * idx + 1] = dscale[1]; dL_dscale[3 * idx + 2] = dscale[2];
+	reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+static GaussCam make_cam(const float* view, const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy) {
+	GaussCam c;
+	c.view = view; c.proj = proj; c.campos = campos; c.W = W; c.H = H;
+	c.tan_fovx = tan_fovx; c.tan_fovy = tan_fovy;
+	c.focal_y = H / (2.0f * tan_fovy);   // DGR rasterizer_impl.cu:228-229
+	c.focal_x = W / (2.0f * tan_fovx);
+	return c;
+}
+
+extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                                 const float* means3D, const float* shs, const float* colors_precomp, const float* normals,
+                                 const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_normal_map,
+                                 float* out_refl_strength_map, float* out_invdepth, int antialiasing, int* radii, int debug, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (!alloc || P < 0 || width <= 0 || height <= 0 || !background || !out_color || !out_normal_map || !out_refl_strength_map) {
+		set_error("gsr_gauss_forward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	if (P == 0) {  // reference: outputs stay zero, num_rendered = 0 (DGR rasterize_points.cu:99-100)
+		GSR_HIP_CHECK(hipMemsetAsync(out_color, 0, HW * 3 * 4, stream));
+		GSR_HIP_CHECK(hipMemsetAsync(out_normal_map, 0, HW * 3 * 4, stream));
+		GSR_HIP_CHECK(hipMemsetAsync(out_refl_strength_map, 0, HW * 4, stream));
+		if (out_invdepth) GSR_HIP_CHECK(hipMemsetAsync(out_invdepth, 0, HW * 4, stream));
+		return 0;
+	}
+	if (!means3D || !opacities || !normals || !refl_strengths || !viewmatrix || !projmatrix || !cam_pos || !radii ||
+	    (!shs && !colors_precomp) || ((!scales || !rotations) && !cov3D_precomp)) {
+		set_error("gsr_gauss_forward: missing required input pointer");
+		return GSR_E_INVALID;
+	}
+	if (D < 0 || D > 3 || (shs && (D + 1) * (D + 1) > M)) { set_error("gsr_gauss_forward: SH degree %d not supported with M=%d", D, M); return GSR_E_INVALID; }
+	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+	const int ntiles = tiles_x * tiles_y;
+
+	size_t geom_bytes = 0, img_bytes = 0;
+	const size_t scan_bytes = scan_temp_bytes(P);
+	carve_geom(nullptr, P, G_REC_F4, 6, G_ACC_F, scan_bytes, &geom_bytes);
+	carve_image(nullptr, HW, ntiles, 1, 1, &img_bytes);
+	void* gbuf = alloc(alloc_user, GSR_BUF_GEOM, geom_bytes);
+	void* ibuf = alloc(alloc_user, GSR_BUF_IMAGE, img_bytes);
+	if (!gbuf || !ibuf) { set_error("workspace allocation failed (%zu / %zu bytes)", geom_bytes, img_bytes); return GSR_E_ALLOC; }
+	GeomState geom = carve_geom(gbuf, P, G_REC_F4, 6, G_ACC_F, scan_bytes, nullptr);
+	ImageState img = carve_image(ibuf, HW, ntiles, 1, 1, nullptr);
+
+	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
+	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+	gauss_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+	                                                             colors_precomp, normals, refl_strengths, cam, radii, geom, tiles_x, tiles_y,
+	                                                             prefiltered, antialiasing);
+	GSR_LAUNCH_CHECK(debug, stream);
+
+	BinningState bin;
+	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
+	if (R < 0) return R;
+
+	const int nblocks = ((ntiles + 7) / 8) * 8;
+	if (out_invdepth)
+		gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		                                                          img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
+		                                                          out_invdepth);
+	else
+		gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		                                                           img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
+		                                                           nullptr);
+	GSR_LAUNCH_CHECK(debug, stream);
+	return R;
+}
+
+extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* normals, const float* refl_strengths,
+                                  const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                  float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer, void* binning_buffer, void* image_buffer,
+                                  const float* dL_dpix, const float* dL_dnormal_map, const float* dL_drefl_strength_map,
+                                  const float* dL_invdepths, float* dL_dmean2D, float* dL_dmean2D_pixels, float* dL_dconic, float* dL_dopacity,
+                                  float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth, float* dL_dmean3D,
+                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing, int debug, void* stream_) {
+	(void)colors_precomp; (void)normals; (void)refl_strengths;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_gauss_backward: invalid size"); return GSR_E_INVALID; }
+	if (P == 0) return 0;
+	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer) || !dL_dpix || !dL_dnormal_map || !dL_drefl_strength_map || !dL_dmean2D ||
+	    !dL_dmean2D_pixels || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dnormals || !dL_drefl_strengths || !dL_dmean3D || !dL_dcov3D ||
+	    !dL_dscale || !dL_drot || (shs && !dL_dsh) || (dL_invdepths && !dL_dinvdepth) || !radii || !means3D || !opacities) {
+		set_error("gsr_gauss_backward: missing required pointer");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+	const int ntiles = tiles_x * tiles_y;
+	GeomState geom = carve_geom(geom_buffer, P, G_REC_F4, 6, G_ACC_F, scan_temp_bytes(P), nullptr);
+	ImageState img = carve_image(image_buffer, HW, ntiles, 1, 1, nullptr);
+	BinningState bin = carve_binning(binning_buffer, R, 0, nullptr);
+
+	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * G_ACC_F * sizeof(float), stream));
+	if (R > 0) {
+		const int nblocks = ((ntiles + 7) / 8) * 8;
+		if (dL_invdepths)
+			gauss_render_bwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                          img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
+			                                                          dL_invdepths, geom.acc);
+		else
+			gauss_render_bwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                           img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
+			                                                           nullptr, geom.acc);
+		GSR_LAUNCH_CHECK(debug, stream);
+	}
+	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+	const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : geom.aux;
+	gauss_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,
+	                                                                 scale_modifier, cov3D_ptr, cam, geom.acc, dL_invdepths ? 1 : 0, antialiasing,
+	                                                                 dL_dmean2D, dL_dmean2D_pixels, dL_dconic, dL_dopacity, dL_dcolor, dL_dnormals,
+	                                                                 dL_drefl_strengths, dL_dinvdepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+	                                                                 dL_drot);
+	GSR_LAUNCH_CHECK(debug, stream);
+	return 0;
+}

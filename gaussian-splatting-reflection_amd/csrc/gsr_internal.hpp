@@ -1,0 +1,174 @@
+// Internal declarations shared by the gfx950 kernels of libgsr_hip.so.
+// Wave = 64 lanes everywhere; tiles are 16x16 pixels = 4 waves of 8x8 pixels.
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <hip/hip_runtime.h>
+#include "../../include/gsr_hip.h"
+
+#define GSR_TILE 16
+#define GSR_TILE_PIX 256
+
+namespace gsr {
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const char* fmt, ...);
+#define GSR_HIP_CHECK(expr)                                                                       \
+	do {                                                                                          \
+		hipError_t _e = (expr);                                                                   \
+		if (_e != hipSuccess) {                                                                   \
+			gsr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+			return GSR_E_HIP;                                                                     \
+		}                                                                                         \
+	} while (0)
+// After a kernel launch: always catch launch errors; with debug also synchronise (reference CHECK_CUDA,
+// DSR auxiliary.h:300-307).
+#define GSR_LAUNCH_CHECK(debug, stream)                                  \
+	do {                                                                 \
+		GSR_HIP_CHECK(hipGetLastError());                                \
+		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));          \
+	} while (0)
+
+// ------------------------------------------------------------------ workspace carving
+// Bump allocation with 256-byte alignment inside the three opaque buffers (the reference's
+// obtain()/required(), DSR rasterizer_impl.h:21-73, with a private layout).
+struct Carver {
+	char* base;
+	size_t off;
+	explicit Carver(void* b) : base((char*)b), off(0) {}
+	template <class T> T* take(size_t count) {
+		off = (off + 255) & ~(size_t)255;
+		T* p = base ? (T*)(base + off) : nullptr;
+		off += count * sizeof(T);
+		return p;
+	}
+	size_t size() const { return (off + 255) & ~(size_t)255; }
+};
+
+// Per-Gaussian state common to both variants.  `rec` is the render record gathered by the tile
+// kernels: REC_F4 float4 per Gaussian (G: 4 = 64 B, S: 5 = 80 B), written by preprocess.
+struct GeomState {
+	float* depths;           // P        view-space z (sort key low word)
+	float2* means2D;         // P        pixel-space centre
+	uint32_t* rect;          // P        packed tile rect: xmin | ymin<<8 ... see pack_rect (2 words)
+	uint32_t* tiles_touched; // P
+	uint32_t* point_offsets; // P        inclusive scan
+	uint8_t* clamped;        // P        bit c set = SH colour channel c clamped at 0
+	float4* rec;             // P*REC_F4
+	float* aux;              // G: cov3D P*6.  S: unused
+	float* acc;              // backward accumulator P*ACC_F (zeroed by backward)
+	int* flags;              // 4 ints: [0] prefiltered-trap flag
+	void* scan_temp;
+	size_t scan_temp_bytes;
+};
+struct ImageState {
+	uint2* ranges;       // tiles
+	float* final_T;      // planes_T * H*W
+	uint32_t* n_contrib; // planes_n * H*W
+};
+struct BinningState {
+	uint64_t* keys_unsorted;
+	uint64_t* keys;
+	uint32_t* vals_unsorted;
+	uint32_t* point_list;
+	void* sort_temp;
+	size_t sort_temp_bytes;
+};
+
+GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_floats, size_t scan_temp_bytes, size_t* total);
+ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int planes_n, size_t* total);
+BinningState carve_binning(void* buf, size_t R, size_t sort_temp_bytes, size_t* total);
+
+size_t scan_temp_bytes(size_t P);
+size_t sort_temp_bytes(size_t R, int end_bit);
+uint32_t higher_msb(uint32_t n);
+
+// Binning pipeline shared by both variants (reference: DSR/DGR rasterizer_impl.cu:282-325):
+// inclusive scan of tiles_touched -> num_rendered (pinned 4-byte readback) -> binning buffer via alloc
+// -> key/value emission -> radix sort -> tile ranges.  Returns num_rendered or <0.
+int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom,
+                const ImageState& img, BinningState* out_binning, int debug, hipStream_t stream);
+
+}  // namespace gsr
+
+// ------------------------------------------------------------------ device helpers
+#ifdef __HIPCC__
+namespace gsr {
+
+__device__ __forceinline__ int f2i(float v) { return (int)v; }  // v_cvt_i32_f32: saturating, NaN -> 0
+
+// getRect (DSR auxiliary.h:71-81 / DGR auxiliary.h:45-55)
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, uint32_t& x0, uint32_t& y0,
+                                         uint32_t& x1, uint32_t& y1) {
+	const float r = (float)max_radius;
+	x0 = (uint32_t)min(gx, max(0, f2i((px - r) / 16.0f)));
+	y0 = (uint32_t)min(gy, max(0, f2i((py - r) / 16.0f)));
+	x1 = (uint32_t)min(gx, max(0, f2i((px + r + 15.0f) / 16.0f)));
+	y1 = (uint32_t)min(gy, max(0, f2i((py + r + 15.0f) / 16.0f)));
+}
+
+// ---- wave64 sums.  Classic GCN reduction: row_shr 1,2,4,8 inside each row of 16 lanes, then
+// row_bcast:15 / row_bcast:31 across the four rows; the total lands in lane 63.  hipcc does not fuse
+// __builtin_amdgcn_update_dpp into the add (it emits v_mov_b32_dpp + v_pk_add_f32 + a zeroing move), so the
+// multi-value forms below issue the fused `v_add_f32_dpp` directly: one VALU instruction per value per
+// step.  Values are interleaved inside one asm statement so that consecutive DPP reads of a register are
+// always >= 3 instructions after its last write (gfx9 VALU-write -> DPP-read hazard: 2 wait states; the
+// compiler's hazard recogniser does not look inside asm, hence the leading s_nop).
+#define GSR_DPP1(CTRL, i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL "\n\t"
+#define GSR_DPP8(CTRL) GSR_DPP1(CTRL, 0) GSR_DPP1(CTRL, 1) GSR_DPP1(CTRL, 2) GSR_DPP1(CTRL, 3) GSR_DPP1(CTRL, 4) GSR_DPP1(CTRL, 5) GSR_DPP1(CTRL, 6) GSR_DPP1(CTRL, 7)
+#define GSR_DPP4(CTRL) GSR_DPP1(CTRL, 0) GSR_DPP1(CTRL, 1) GSR_DPP1(CTRL, 2) GSR_DPP1(CTRL, 3)
+#define GSR_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define GSR_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define GSR_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define GSR_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define GSR_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define GSR_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+// Sum 8 independent values across the wave; totals valid in lane 63 only.  Must be called with all 64
+// lanes active (wave-uniform control flow).
+__device__ __forceinline__ void wave_sum8(float* v) {
+	asm volatile("s_nop 1\n\t" GSR_DPP8(GSR_SHR1) GSR_DPP8(GSR_SHR2) GSR_DPP8(GSR_SHR4) GSR_DPP8(GSR_SHR8) GSR_DPP8(GSR_BC15) GSR_DPP8(GSR_BC31)
+	             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void wave_sum4(float* v) {
+	asm volatile("s_nop 1\n\t" GSR_DPP4(GSR_SHR1) GSR_DPP4(GSR_SHR2) GSR_DPP4(GSR_SHR4) GSR_DPP4(GSR_SHR8) GSR_DPP4(GSR_BC15) GSR_DPP4(GSR_BC31)
+	             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+// single value (compiler-scheduled form; used off the hot path)
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+	int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
+	return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+	v = dpp_add<0x111>(v);
+	v = dpp_add<0x112>(v);
+	v = dpp_add<0x114>(v);
+	v = dpp_add<0x118>(v);
+	v = dpp_add<0x142, 0xA>(v);
+	v = dpp_add<0x143, 0xC>(v);
+	return v;  // total in lane 63
+}
+__device__ __forceinline__ float wave_max_pos(float v) {  // max over lanes of non-negative values; total in lane 63
+	int m;
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); v = fmaxf(v, __int_as_float(m));
+	return v;
+}
+
+// XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so
+// give each XCD a contiguous band of tiles (neighbouring tiles gather the same Gaussian records and
+// then hit the same L2).  Pure performance; any mapping is correct.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles) {
+	const uint32_t nx = 8;
+	const uint32_t per = (ntiles + nx - 1) / nx;
+	uint32_t t = (bid % nx) * per + bid / nx;
+	return t;  // may be >= ntiles for the ragged tail: caller launches per*8 blocks and checks
+}
+
+}  // namespace gsr
+#endif

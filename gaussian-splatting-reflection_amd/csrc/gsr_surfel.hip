@@ -1,0 +1,765 @@
+// Variant S — 2D Gaussian surfels (ray-splat intersection, 8-plane auxiliary map, reflection strength,
+// env-scope mask, per-Gaussian max blend weight).  MI355X-native restatement of the behaviour of
+// submodules/diff-surfel-rasterization (DSR cuda_rasterizer/forward.cu, backward.cu, rasterizer_impl.cu),
+// the rasterizer gaussian_renderer/__init__.py:14,130 of the reference calls.  Design notes in DESIGN.md.
+//
+// Render record (80 bytes, five float4 per Gaussian, written by preprocess, gathered by the tile kernels):
+//   f4[0] = (x, y, Tu.x, Tu.y)   f4[1] = (Tu.z, Tv.x, Tv.y, Tv.z)   f4[2] = (Tw.x, Tw.y, Tw.z, n.x)
+//   f4[3] = (n.y, n.z, opacity, r)   f4[4] = (g, b, refl, mask)
+#include "gsr_internal.hpp"
+#include "gsr_math.hpp"
+
+namespace gsr {
+
+#define S_REC_F4 5
+#define S_ACC_F 20
+#define SA_COLOR 0
+#define SA_REFL 3
+#define SA_NORMAL 4
+#define SA_OPAC 7
+#define SA_T 8
+#define SA_MEAN2D 17
+
+#define S_NEAR 0.2f
+#define S_FAR 100.0f
+#define S_FILTER_INV_SQ 2.0f
+
+struct SurfelCam {
+	const float* view;
+	const float* proj;
+	const float* campos;
+	int W, H;
+	float tan_fovx, tan_fovy, focal_x, focal_y;
+};
+
+// quat_to_rotmat (DSR auxiliary.h:217-239); the reference's rsqrtf is restated as an exact 1/sqrt.
+__device__ __forceinline__ M3 quat_to_rotmat(const float* __restrict__ q, float& w, float& x, float& y, float& z) {
+#pragma clang fp contract(off)
+	const float s = 1.0f / sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+	w = q[0] * s; x = q[1] * s; y = q[2] * s; z = q[3] * s;
+	return m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y), 2.f * (x * y - w * z),
+	               1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x), 2.f * (x * z + w * y), 2.f * (y * z - w * x),
+	               1.f - 2.f * (x * x + y * y));
+}
+
+// P = world2ndc * ndc2pix as a 3-column x 4-row matrix (DSR forward.cu:99-112, backward.cu:520-533):
+// P[j][k] = sum_m world2ndc[m][k] * ndc2pix[j][m], world2ndc[m][k] = proj[m + 4k].
+struct P34 {
+	float m[3][4];
+};
+__device__ __forceinline__ P34 make_P(const float* __restrict__ pm, int W, int H) {
+#pragma clang fp contract(off)
+	const float Wh = (float)(float(W) / 2.0), Wm = (float)(float(W - 1) / 2.0);
+	const float Hh = (float)(float(H) / 2.0), Hm = (float)(float(H - 1) / 2.0);
+	P34 p;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		p.m[0][k] = pm[0 + 4 * k] * Wh + pm[3 + 4 * k] * Wm;
+		p.m[1][k] = pm[1 + 4 * k] * Hh + pm[3 + 4 * k] * Hm;
+		p.m[2][k] = pm[3 + 4 * k];
+	}
+	return p;
+}
+
+// compute_transmat (DSR forward.cu:75-115): T = (splat2world^T * world2ndc) * ndc2pix, evaluated in that
+// association and left-to-right order (zero terms of the 4-vectors dropped: adding an exact zero is exact).
+__device__ __forceinline__ void compute_transmat(float px, float py, float pz, const float* __restrict__ scale, float mod,
+                                                 const float* __restrict__ rot, const SurfelCam& cam, M3& T, F3& normal) {
+#pragma clang fp contract(off)
+	float qw, qx, qy, qz;
+	const M3 R = quat_to_rotmat(rot, qw, qx, qy, qz);
+	const float s0 = mod * scale[0], s1 = mod * scale[1];
+	const float L0[3] = {R.m[0][0] * s0, R.m[0][1] * s0, R.m[0][2] * s0};
+	const float L1[3] = {R.m[1][0] * s1, R.m[1][1] * s1, R.m[1][2] * s1};
+	const float* pm = cam.proj;
+	// AB[j][i], j = 0..3 (ndc component), i = 0..2 (u, v, 1)
+	float AB[4][3];
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		AB[j][0] = L0[0] * pm[j] + L0[1] * pm[j + 4] + L0[2] * pm[j + 8];
+		AB[j][1] = L1[0] * pm[j] + L1[1] * pm[j + 4] + L1[2] * pm[j + 8];
+		AB[j][2] = px * pm[j] + py * pm[j + 4] + pz * pm[j + 8] + pm[j + 12];
+	}
+	const float Wh = (float)(float(cam.W) / 2.0), Wm = (float)(float(cam.W - 1) / 2.0);
+	const float Hh = (float)(float(cam.H) / 2.0), Hm = (float)(float(cam.H - 1) / 2.0);
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+		T.m[0][i] = AB[0][i] * Wh + AB[3][i] * Wm;
+		T.m[1][i] = AB[1][i] * Hh + AB[3][i] * Hm;
+		T.m[2][i] = AB[3][i];
+	}
+	const float* vm = cam.view;
+	const float nx = R.m[2][0], ny = R.m[2][1], nz = R.m[2][2];
+	normal = f3(vm[0] * nx + vm[4] * ny + vm[8] * nz, vm[1] * nx + vm[5] * ny + vm[9] * nz, vm[2] * nx + vm[6] * ny + vm[10] * nz);
+}
+
+// preprocessCUDA forward (DSR forward.cu:149-253); FMA contraction off (integer outputs bit-exact vs oracle).
+__global__ void __launch_bounds__(256)
+surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                         const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                         const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
+                         const float* __restrict__ refl, const uint8_t* __restrict__ env_scope_mask, SurfelCam cam, int* __restrict__ radii,
+                         GeomState g, int gx, int gy, int prefiltered) {
+#pragma clang fp contract(off)
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	radii[idx] = 0;
+	g.tiles_touched[idx] = 0;
+	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
+	const float* vm = cam.view;
+	const float pvx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+	const float pvy = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+	const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+	if (pvz <= 0.2f) {
+		if (prefiltered) g.flags[0] = 1;
+		return;
+	}
+	M3 T;
+	F3 normal;
+	if (transMat_precomp == nullptr) {
+		compute_transmat(mx, my, mz, scales + 2 * idx, scale_modifier, rotations + 4 * idx, cam, T, normal);
+	} else {
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+#pragma unroll
+			for (int r = 0; r < 3; r++) T.m[c][r] = transMat_precomp[9 * idx + 3 * c + r];
+		normal = f3(0.0f, 0.0f, 1.0f);
+	}
+	// DUAL_VISIABLE (forward.cu:211-216)
+	const float cosv = -((pvx * normal.x) + (pvy * normal.y) + (pvz * normal.z));
+	if (cosv == 0) return;
+	const float multiplier = cosv > 0 ? 1.f : -1.f;
+	normal = f3(multiplier * normal.x, multiplier * normal.y, multiplier * normal.z);
+	// compute_aabb (forward.cu:119-145), cutoff = 3
+	const float cutoff = 3.0f;
+	const float t0 = cutoff * cutoff, t1 = cutoff * cutoff, t2 = -1.0f;
+	const float d = t0 * (T.m[2][0] * T.m[2][0]) + t1 * (T.m[2][1] * T.m[2][1]) + t2 * (T.m[2][2] * T.m[2][2]);
+	if (d == 0.0f) return;
+	const float inv_d = 1 / d;
+	const float f0 = inv_d * t0, f1 = inv_d * t1, f2 = inv_d * t2;
+	const float pxi = f0 * (T.m[0][0] * T.m[2][0]) + f1 * (T.m[0][1] * T.m[2][1]) + f2 * (T.m[0][2] * T.m[2][2]);
+	const float pyi = f0 * (T.m[1][0] * T.m[2][0]) + f1 * (T.m[1][1] * T.m[2][1]) + f2 * (T.m[1][2] * T.m[2][2]);
+	const float h0x = pxi * pxi - (f0 * (T.m[0][0] * T.m[0][0]) + f1 * (T.m[0][1] * T.m[0][1]) + f2 * (T.m[0][2] * T.m[0][2]));
+	const float h0y = pyi * pyi - (f0 * (T.m[1][0] * T.m[1][0]) + f1 * (T.m[1][1] * T.m[1][1]) + f2 * (T.m[1][2] * T.m[1][2]));
+	const float ex = sqrtf(fmaxf(1e-4f, h0x)), ey = sqrtf(fmaxf(1e-4f, h0y));
+	const float radius = ceilf(fmaxf(fmaxf(ex, ey), cutoff * (float)0.707106));
+	uint32_t x0, y0, x1, y1;
+	get_rect(pxi, pyi, f2i(radius), gx, gy, x0, y0, x1, y1);
+	if ((x1 - x0) * (y1 - y0) == 0) return;
+
+	float cr, cg, cb;
+	if (colors_precomp == nullptr) {
+		const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+		ShRow s;
+		load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+		const F3 c = sh_eval(D, s, dx / len, dy / len, dz / len);
+		g.clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
+		cr = fmaxf(c.x, 0.0f); cg = fmaxf(c.y, 0.0f); cb = fmaxf(c.z, 0.0f);
+	} else {
+		cr = colors_precomp[3 * idx]; cg = colors_precomp[3 * idx + 1]; cb = colors_precomp[3 * idx + 2];
+	}
+	g.depths[idx] = pvz;
+	radii[idx] = f2i(radius);
+	g.means2D[idx] = make_float2(pxi, pyi);
+	g.rect[2 * idx] = x0 | (y0 << 16);
+	g.rect[2 * idx + 1] = x1 | (y1 << 16);
+	const float maskv = (env_scope_mask != nullptr && env_scope_mask[idx]) ? 1.0f : 0.0f;
+	float4* rec = g.rec + (size_t)idx * S_REC_F4;
+	rec[0] = make_float4(pxi, pyi, T.m[0][0], T.m[0][1]);
+	rec[1] = make_float4(T.m[0][2], T.m[1][0], T.m[1][1], T.m[1][2]);
+	rec[2] = make_float4(T.m[2][0], T.m[2][1], T.m[2][2], normal.x);
+	rec[3] = make_float4(normal.y, normal.z, opacities[idx], cr);
+	rec[4] = make_float4(cg, cb, refl[idx], maskv);
+	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
+}
+
+// Ray-splat intersection and falloff for one (pixel, surfel) pair, shared by the forward and backward
+// tile kernels (DSR forward.cu:362-410, backward.cu:292-336).  EPS is the `unstable` threshold: 1e-4 in
+// the forward, 1e-6 in the backward — a quirk of the reference that is reproduced on purpose.
+struct SurfelPair {
+	float kx, ky, kz, lx, ly, lz, pz, sx, sy, dx, dy, rho3d, rho2d, depth, G, alpha;
+};
+template <bool FWD>
+__device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, const float4 r2, float opac, float pixx, float pixy, SurfelPair& o) {
+#pragma clang fp contract(off)
+	const float Tux = r0.z, Tuy = r0.w, Tuz = r1.x, Tvx = r1.y, Tvy = r1.z, Tvz = r1.w, Twx = r2.x, Twy = r2.y, Twz = r2.z;
+	o.kx = fmaf(pixx, Twx, -Tux); o.ky = fmaf(pixx, Twy, -Tuy); o.kz = fmaf(pixx, Twz, -Tuz);
+	o.lx = fmaf(pixy, Twx, -Tvx); o.ly = fmaf(pixy, Twy, -Tvy); o.lz = fmaf(pixy, Twz, -Tvz);
+	const float ppx = fmaf(o.ky, o.lz, -(o.kz * o.ly));
+	const float ppy = fmaf(o.kz, o.lx, -(o.kx * o.lz));
+	o.pz = fmaf(o.kx, o.ly, -(o.ky * o.lx));
+	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
+	if (!unstable) {
+		const float inv_pz = 1.0f / o.pz;
+		o.sx = ppx * inv_pz;
+		o.sy = ppy * inv_pz;
+	} else {
+		o.sx = 0.f;
+		o.sy = 0.f;
+	}
+	o.rho3d = unstable ? 1e8f : fmaf(o.sx, o.sx, o.sy * o.sy);
+	o.dx = r0.x - pixx;
+	o.dy = r0.y - pixy;
+	o.rho2d = S_FILTER_INV_SQ * fmaf(o.dx, o.dx, o.dy * o.dy);
+	const float rho = fminf(o.rho3d, o.rho2d);
+	o.depth = fmaf(o.sx, Twx, o.sy * Twy) + Twz;
+	if (o.depth < S_NEAR) return false;
+	const float power = -0.5f * rho;
+	if (power > 0.0f) return false;
+	o.G = __expf(power);
+	o.alpha = fminf(0.99f, opac * o.G);
+	return !(o.alpha < 1.0f / 255.0f);
+}
+
+// renderCUDA forward (DSR forward.cu:258-489)
+__global__ void __launch_bounds__(256)
+surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                         const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
+                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_others,
+                         float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
+	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+	if (tile >= (uint32_t)ntiles) return;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixx = (float)px, pixy = (float)py;
+	const uint2 range = ranges[tile];
+	const int count = (int)(range.y - range.x);
+
+	constexpr int BATCH = 128;
+	__shared__ float4 s_rec[BATCH * S_REC_F4];   // 10 KB
+	__shared__ uint32_t s_id[BATCH];
+	__shared__ float s_wmax[4][BATCH];           // per-wave max blend weight of this batch
+	__shared__ int s_done[4];
+
+	bool done = !inside;
+	float T = 1.0f;
+	uint32_t last_contributor = 0;
+	float C0 = 0, C1 = 0, C2 = 0, RS = 0, mask = 0;
+	float N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+	float median_contributor = -1.0f;
+
+	for (int base = 0; base < count; base += BATCH) {
+		const bool wave_done = __ballot(!done) == 0ull;
+		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+		__syncthreads();  // also: previous batch's s_wmax flush finished
+		if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == 4) break;
+		const int nb = min(BATCH, count - base);
+		for (int item = tid; item < nb * S_REC_F4; item += 256) {
+			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
+			const uint32_t id = point_list[range.x + base + i];
+			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
+			if (q == 0) s_id[i] = id;
+		}
+		if (tid < BATCH) { s_wmax[0][tid] = 0.f; s_wmax[1][tid] = 0.f; s_wmax[2][tid] = 0.f; s_wmax[3][tid] = 0.f; }
+		__syncthreads();
+		if (!wave_done) {
+			for (int j = 0; j < nb; j++) {
+				const float4 r0 = s_rec[j * S_REC_F4 + 0];
+				const float4 r1 = s_rec[j * S_REC_F4 + 1];
+				const float4 r2 = s_rec[j * S_REC_F4 + 2];
+				const float4 r3 = s_rec[j * S_REC_F4 + 3];
+				SurfelPair o;
+				bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
+				float test_T = 0.f;
+				if (ok) {
+					test_T = T * (1 - o.alpha);
+					if (test_T < 0.0001f) {
+						done = true;
+						ok = false;
+					}
+				}
+				if (__ballot(ok) != 0ull) {
+					const float4 r4 = s_rec[j * S_REC_F4 + 4];
+					float w = 0.f;
+					if (ok) {
+						w = o.alpha * T;
+						const float A = 1 - T;
+						const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR / o.depth);
+						distortion += (m * m * A + M2 - 2 * m * M1) * w;
+						Dp += o.depth * w;
+						M1 += m * w;
+						M2 += m * m * w;
+						if (T > 0.5f) {
+							median_depth = o.depth;
+							median_contributor = (float)(base + j + 1);
+						}
+						N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
+						C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
+						RS = fmaf(r4.z, w, RS);
+						if (r4.w != 0.f) mask = 1.0f;
+						T = test_T;
+						last_contributor = (uint32_t)(base + j + 1);
+					}
+					// gaussian_weights (forward.cu:458-459): max over the wave's pixels, merged per tile below
+					const float wm = wave_max_pos(w);
+					if (lane == 63) s_wmax[wave][j] = wm;
+				} else if (__ballot(!done) == 0ull) {
+					break;
+				}
+			}
+		}
+		__syncthreads();
+		if (tid < nb) {
+			const float m = fmaxf(fmaxf(s_wmax[0][tid], s_wmax[1][tid]), fmaxf(s_wmax[2][tid], s_wmax[3][tid]));
+			// w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
+			// check-then-atomicExch is racy, this is the true maximum
+			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + s_id[tid], __float_as_int(m));
+		}
+	}
+	if (inside) {
+		const size_t HW = (size_t)H * W;
+		const size_t pix = (size_t)W * py + px;
+		final_T[pix] = T;
+		final_T[HW + pix] = M1;
+		final_T[2 * HW + pix] = M2;
+		n_contrib[pix] = last_contributor;
+		n_contrib[HW + pix] = (uint32_t)median_contributor;  // v_cvt_u32_f32 saturates: -1 -> 0, as cvt.rzi.u32.f32 does
+		out_color[pix] = C0 + T * bg[0];
+		out_color[HW + pix] = C1 + T * bg[1];
+		out_color[2 * HW + pix] = C2 + T * bg[2];
+		out_refl[pix] = RS;
+		out_others[0 * HW + pix] = Dp;
+		out_others[1 * HW + pix] = 1 - T;
+		out_others[2 * HW + pix] = N0;
+		out_others[3 * HW + pix] = N1;
+		out_others[4 * HW + pix] = N2;
+		out_others[5 * HW + pix] = median_depth;
+		out_others[6 * HW + pix] = distortion;
+		out_others[7 * HW + pix] = mask;
+	}
+}
+
+// renderCUDA backward (DSR backward.cu:143-470).  ~19 atomics per pair in the reference; here: DPP wave
+// reduction -> per-wave LDS slab -> one 80-byte row of float atomics per (tile, surfel) into acc[P][20].
+#define S_BWD_BATCH 64
+__global__ void __launch_bounds__(256)
+surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                         const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_Ts,
+                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
+                         const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
+	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
+	if (tile >= (uint32_t)ntiles) return;
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixx = (float)px, pixy = (float)py;
+	const uint2 range = ranges[tile];
+	const int count = (int)(range.y - range.x);
+	const size_t HW = (size_t)H * W;
+	const size_t pix = (size_t)W * py + px;
+
+	__shared__ float4 s_rec[S_BWD_BATCH * S_REC_F4];
+	__shared__ uint32_t s_id[S_BWD_BATCH];
+	__shared__ float4 s_slab[4][S_BWD_BATCH][S_ACC_F / 4];
+	__shared__ unsigned long long s_touched[4];
+
+	const float T_final = inside ? final_Ts[pix] : 0.f;
+	float T = T_final;
+	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+	const int median_contributor = inside ? (int)n_contrib[HW + pix] : 0;
+	float dp0 = 0, dp1 = 0, dp2 = 0, dr = 0;
+	float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dnx = 0, dny = 0, dnz = 0, dL_dmedian_depth = 0;
+	if (inside) {
+		dp0 = dL_dpixels[pix]; dp1 = dL_dpixels[HW + pix]; dp2 = dL_dpixels[2 * HW + pix];
+		dr = dL_drefl_map[pix];
+		dL_ddepth = dL_depths[0 * HW + pix];
+		dL_daccum = dL_depths[1 * HW + pix];
+		dnx = dL_depths[2 * HW + pix]; dny = dL_depths[3 * HW + pix]; dnz = dL_depths[4 * HW + pix];
+		dL_dmedian_depth = dL_depths[5 * HW + pix];
+		dL_dreg = dL_depths[6 * HW + pix];
+	}
+	const float final_D = inside ? final_Ts[HW + pix] : 0.f;
+	const float final_D2 = inside ? final_Ts[2 * HW + pix] : 0.f;
+	const float final_A = 1 - T_final;
+	float last_dL_dT = 0;
+	float acc_c0 = 0, acc_c1 = 0, acc_c2 = 0, acc_r = 0, acc_depth = 0, acc_alpha = 0, acc_n0 = 0, acc_n1 = 0, acc_n2 = 0;
+	float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, lr = 0, last_depth = 0, ln0 = 0, ln1 = 0, ln2 = 0;
+	const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+
+	for (int base = 0; base < count; base += S_BWD_BATCH) {
+		const int nb = min(S_BWD_BATCH, count - base);
+		__syncthreads();
+		for (int item = tid; item < nb * S_REC_F4; item += 256) {
+			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
+			const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
+			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
+			if (q == 0) s_id[i] = id;
+		}
+		__syncthreads();
+		unsigned long long touched = 0ull;
+		for (int j = 0; j < nb; j++) {
+			const int contributor = count - 1 - (base + j);
+			const float4 r0 = s_rec[j * S_REC_F4 + 0];
+			const float4 r1 = s_rec[j * S_REC_F4 + 1];
+			const float4 r2 = s_rec[j * S_REC_F4 + 2];
+			const float4 r3 = s_rec[j * S_REC_F4 + 3];
+			SurfelPair o;
+			const bool ok = inside && contributor < last_contributor && surfel_pair<false>(r0, r1, r2, r3.z, pixx, pixy, o);
+			if (__ballot(ok) == 0ull) continue;
+			const float4 r4 = s_rec[j * S_REC_F4 + 4];
+			float v[S_ACC_F];
+#pragma unroll
+			for (int q = 0; q < S_ACC_F; q++) v[q] = 0.f;
+			if (ok) {
+				const float alpha = o.alpha, G = o.G, c_d = o.depth;
+				const float Twx = r2.x, Twy = r2.y;
+				T = T / (1.f - alpha);
+				const float dchannel_dcolor = alpha * T;
+				float dL_dalpha = 0.0f;
+				acc_c0 = last_alpha * lc0 + (1.f - last_alpha) * acc_c0; lc0 = r3.w; dL_dalpha += (r3.w - acc_c0) * dp0;
+				acc_c1 = last_alpha * lc1 + (1.f - last_alpha) * acc_c1; lc1 = r4.x; dL_dalpha += (r4.x - acc_c1) * dp1;
+				acc_c2 = last_alpha * lc2 + (1.f - last_alpha) * acc_c2; lc2 = r4.y; dL_dalpha += (r4.y - acc_c2) * dp2;
+				v[SA_COLOR + 0] = dchannel_dcolor * dp0;
+				v[SA_COLOR + 1] = dchannel_dcolor * dp1;
+				v[SA_COLOR + 2] = dchannel_dcolor * dp2;
+				acc_r = last_alpha * lr + (1.f - last_alpha) * acc_r; lr = r4.z;
+				dL_dalpha += (r4.z - acc_r) * dr;
+				v[SA_REFL] = dchannel_dcolor * dr;
+				float dL_dz = 0.0f, dL_dweight = 0.f;
+				const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR / c_d);
+				const float dmd_dd = (S_FAR * S_NEAR) / ((S_FAR - S_NEAR) * c_d * c_d);
+				if (contributor == median_contributor - 1) dL_dz += dL_dmedian_depth;
+				dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+				dL_dalpha += dL_dweight - last_dL_dT;
+				last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+				const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+				dL_dz += dL_dmd * dmd_dd;
+				acc_depth = last_alpha * last_depth + (1.f - last_alpha) * acc_depth; last_depth = c_d;
+				dL_dalpha += (c_d - acc_depth) * dL_ddepth;
+				acc_alpha = last_alpha * 1.0f + (1.f - last_alpha) * acc_alpha;
+				dL_dalpha += (1 - acc_alpha) * dL_daccum;
+				acc_n0 = last_alpha * ln0 + (1.f - last_alpha) * acc_n0; ln0 = r2.w; dL_dalpha += (r2.w - acc_n0) * dnx;
+				acc_n1 = last_alpha * ln1 + (1.f - last_alpha) * acc_n1; ln1 = r3.x; dL_dalpha += (r3.x - acc_n1) * dny;
+				acc_n2 = last_alpha * ln2 + (1.f - last_alpha) * acc_n2; ln2 = r3.y; dL_dalpha += (r3.y - acc_n2) * dnz;
+				v[SA_NORMAL + 0] = alpha * T * dnx;
+				v[SA_NORMAL + 1] = alpha * T * dny;
+				v[SA_NORMAL + 2] = alpha * T * dnz;
+				dL_dalpha *= T;
+				last_alpha = alpha;
+				dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+				const float dL_dG = r3.z * dL_dalpha;
+				dL_dz += alpha * T * dL_ddepth;
+				if (o.rho3d <= o.rho2d) {
+					const float dL_dsx = dL_dG * -G * o.sx + dL_dz * Twx;
+					const float dL_dsy = dL_dG * -G * o.sy + dL_dz * Twy;
+					const float dsx_pz = dL_dsx / o.pz, dsy_pz = dL_dsy / o.pz;
+					const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * o.sx + dsy_pz * o.sy);
+					// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
+					const float dkx = o.ly * dpz - o.lz * dpy, dky = o.lz * dpx - o.lx * dpz, dkz = o.lx * dpy - o.ly * dpx;
+					const float dlx = dpy * o.kz - dpz * o.ky, dly = dpz * o.kx - dpx * o.kz, dlz = dpx * o.ky - dpy * o.kx;
+					v[SA_T + 0] = -dkx; v[SA_T + 1] = -dky; v[SA_T + 2] = -dkz;
+					v[SA_T + 3] = -dlx; v[SA_T + 4] = -dly; v[SA_T + 5] = -dlz;
+					v[SA_T + 6] = pixx * dkx + pixy * dlx + dL_dz * o.sx;
+					v[SA_T + 7] = pixx * dky + pixy * dly + dL_dz * o.sy;
+					v[SA_T + 8] = pixx * dkz + pixy * dlz + dL_dz * 1.0f;
+				} else {
+					const float dG_ddelx = -G * S_FILTER_INV_SQ * o.dx;
+					const float dG_ddely = -G * S_FILTER_INV_SQ * o.dy;
+					v[SA_MEAN2D + 0] = dL_dG * dG_ddelx;
+					v[SA_MEAN2D + 1] = dL_dG * dG_ddely;
+					v[SA_T + 6] = o.sx * dL_dz;
+					v[SA_T + 7] = o.sy * dL_dz;
+					v[SA_T + 8] = dL_dz;
+				}
+				v[SA_OPAC] = G * dL_dalpha;
+			}
+			wave_sum8(v);
+			wave_sum8(v + 8);
+			wave_sum4(v + 16);
+			if (lane == 63) {
+				s_slab[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
+				s_slab[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
+				s_slab[wave][j][2] = make_float4(v[8], v[9], v[10], v[11]);
+				s_slab[wave][j][3] = make_float4(v[12], v[13], v[14], v[15]);
+				s_slab[wave][j][4] = make_float4(v[16], v[17], v[18], 0.f);
+			}
+			touched |= 1ull << j;
+		}
+		if (lane == 0) s_touched[wave] = touched;
+		__syncthreads();
+		for (int item = tid; item < nb * (S_ACC_F / 4); item += 256) {
+			const int i = item / (S_ACC_F / 4), q = item - i * (S_ACC_F / 4);
+			float4 s = make_float4(0, 0, 0, 0);
+			bool any = false;
+#pragma unroll
+			for (int w = 0; w < 4; w++) {
+				if ((s_touched[w] >> i) & 1ull) {
+					const float4 t = s_slab[w][i][q];
+					s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+					any = true;
+				}
+			}
+			if (any) {
+				float* dst = acc + (size_t)s_id[i] * S_ACC_F + q * 4;
+				atomicAdd(dst + 0, s.x);
+				atomicAdd(dst + 1, s.y);
+				atomicAdd(dst + 2, s.z);
+				if (q != 4) atomicAdd(dst + 3, s.w);
+			}
+		}
+	}
+}
+
+// quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
+__device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, const M3& v_R, float* v_quat) {
+	v_quat[0] = 2.f * (x * (v_R.m[1][2] - v_R.m[2][1]) + y * (v_R.m[2][0] - v_R.m[0][2]) + z * (v_R.m[0][1] - v_R.m[1][0]));
+	v_quat[1] = 2.f * (-2.f * x * (v_R.m[1][1] + v_R.m[2][2]) + y * (v_R.m[0][1] + v_R.m[1][0]) + z * (v_R.m[0][2] + v_R.m[2][0]) + w * (v_R.m[1][2] - v_R.m[2][1]));
+	v_quat[2] = 2.f * (x * (v_R.m[0][1] + v_R.m[1][0]) - 2.f * y * (v_R.m[0][0] + v_R.m[2][2]) + z * (v_R.m[1][2] + v_R.m[2][1]) + w * (v_R.m[2][0] - v_R.m[0][2]));
+	v_quat[3] = 2.f * (x * (v_R.m[0][2] + v_R.m[2][0]) + y * (v_R.m[1][2] + v_R.m[2][1]) - 2.f * z * (v_R.m[0][0] + v_R.m[1][1]) + w * (v_R.m[0][1] - v_R.m[1][0]));
+}
+
+// compute_transmat_aabb + preprocessCUDA backward (DSR backward.cu:473-660), one thread per surfel.
+// Writes every output element (zeros for culled surfels).
+__global__ void __launch_bounds__(256)
+surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
+                             const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
+                             const float4* __restrict__ rec, SurfelCam cam, const float* __restrict__ acc, float* __restrict__ dL_dmean2D,
+                             float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                             float* __restrict__ dL_drefl, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat,
+                             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const float4* a4 = reinterpret_cast<const float4*>(acc + (size_t)idx * S_ACC_F);
+	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3], a4v = a4[4];
+	const float gcol[3] = {a0.x, a0.y, a0.z};
+	const float gnrm[3] = {a1.x, a1.y, a1.z};
+	float dT[9] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4v.x};  // render-accumulated dL_dtransMat
+	const float gm2x = a4v.y, gm2y = a4v.z;
+	dL_dcolor[3 * idx] = gcol[0]; dL_dcolor[3 * idx + 1] = gcol[1]; dL_dcolor[3 * idx + 2] = gcol[2];
+	dL_drefl[idx] = a0.w;
+	dL_dnormal[3 * idx] = gnrm[0]; dL_dnormal[3 * idx + 1] = gnrm[1]; dL_dnormal[3 * idx + 2] = gnrm[2];
+	dL_dopacity[idx] = a1.w;
+
+	float dmean[3] = {0.f, 0.f, 0.f}, dscale[2] = {0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+	float out_m2x = gm2x, out_m2y = gm2y;
+	float dTout[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) dTout[i] = dT[i];
+	const bool visible = radii[idx] > 0;
+	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
+	if (visible) {
+		const int Wb = f2i(cam.focal_x * cam.tan_fovx * 2);  // DSR backward.cu:637-638
+		const int Hb = f2i(cam.focal_y * cam.tan_fovy * 2);
+		const bool precomp = (scales == nullptr);
+		M3 T;
+		F3 normal = f3(0.f, 0.f, 0.f);
+		P34 Pm;
+		M3 R;
+		float qw = 0, qx = 0, qy = 0, qz = 0, sc0 = 0, sc1 = 0;
+		const float4* rc = rec + (size_t)idx * S_REC_F4;
+		if (precomp) {
+			const float4 r0 = rc[0], r1 = rc[1], r2 = rc[2];
+			T = m3_make(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z);
+		} else {
+			R = quat_to_rotmat(rotations + 4 * idx, qw, qx, qy, qz);
+			sc0 = scales[2 * idx]; sc1 = scales[2 * idx + 1];   // scale_to_mat(scale, 1.0f): scale_modifier ignored (backward.cu:511)
+			const float L0[3] = {R.m[0][0] * sc0, R.m[0][1] * sc0, R.m[0][2] * sc0};
+			const float L1[3] = {R.m[1][0] * sc1, R.m[1][1] * sc1, R.m[1][2] * sc1};
+			Pm = make_P(cam.proj, Wb, Hb);
+#pragma unroll
+			for (int j = 0; j < 3; j++) {
+				T.m[j][0] = L0[0] * Pm.m[j][0] + L0[1] * Pm.m[j][1] + L0[2] * Pm.m[j][2];
+				T.m[j][1] = L1[0] * Pm.m[j][0] + L1[1] * Pm.m[j][1] + L1[2] * Pm.m[j][2];
+				T.m[j][2] = mx * Pm.m[j][0] + my * Pm.m[j][1] + mz * Pm.m[j][2] + Pm.m[j][3];
+			}
+			const float* vm = cam.view;
+			const float nx = R.m[2][0], ny = R.m[2][1], nz = R.m[2][2];
+			normal = f3(vm[0] * nx + vm[4] * ny + vm[8] * nz, vm[1] * nx + vm[5] * ny + vm[9] * nz, vm[2] * nx + vm[6] * ny + vm[10] * nz);
+		}
+		M3 dL_dT = m3_make(dT[0], dT[1], dT[2], dT[3], dT[4], dT[5], dT[6], dT[7], dT[8]);
+		bool early = false;
+		if (gm2x != 0 || gm2y != 0) {
+			// gradient of the AABB centre w.r.t. T (backward.cu:545-573)
+			const float tv[3] = {9.0f, 9.0f, -1.0f};
+			const float d = tv[0] * (T.m[2][0] * T.m[2][0]) + tv[1] * (T.m[2][1] * T.m[2][1]) + tv[2] * (T.m[2][2] * T.m[2][2]);
+			const float invd = 1.0f / d;
+			float fv[3], dL_df[3], dT3[3];
+#pragma unroll
+			for (int r = 0; r < 3; r++) fv[r] = tv[r] * invd;
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				dL_dT.m[0][r] += gm2x * fv[r] * T.m[2][r];
+				dL_dT.m[1][r] += gm2y * fv[r] * T.m[2][r];
+				dT3[r] = gm2x * fv[r] * T.m[0][r] + gm2y * fv[r] * T.m[1][r];
+				dL_df[r] = gm2x * T.m[0][r] * T.m[2][r] + gm2y * T.m[1][r] * T.m[2][r];
+			}
+			const float dL_dd = (float)((double)(dL_df[0] * fv[0] + dL_df[1] * fv[1] + dL_df[2] * fv[2]) * (-1.0 / (double)d));
+#pragma unroll
+			for (int r = 0; r < 3; r++) dL_dT.m[2][r] += dT3[r] + dL_dd * (tv[r] * T.m[2][r] * 2.0f);
+			if (precomp) {
+#pragma unroll
+				for (int c = 0; c < 3; c++)
+#pragma unroll
+					for (int r = 0; r < 3; r++) dTout[3 * c + r] = dL_dT.m[c][r];
+				early = true;
+			}
+		}
+		if (!precomp && !early) {
+			// dL_dM = P * dL_dT^T  (4 rows x 3 cols); only rows 0..2 are used
+			float dM[3][3];
+#pragma unroll
+			for (int j = 0; j < 3; j++)
+#pragma unroll
+				for (int r = 0; r < 3; r++) dM[j][r] = Pm.m[0][r] * dL_dT.m[0][j] + Pm.m[1][r] * dL_dT.m[1][j] + Pm.m[2][r] * dL_dT.m[2][j];
+			const float* vm = cam.view;
+			float tnx = vm[0] * gnrm[0] + vm[1] * gnrm[1] + vm[2] * gnrm[2];
+			float tny = vm[4] * gnrm[0] + vm[5] * gnrm[1] + vm[6] * gnrm[2];
+			float tnz = vm[8] * gnrm[0] + vm[9] * gnrm[1] + vm[10] * gnrm[2];
+			const float pvx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+			const float pvy = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+			const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+			const float cosv = -((pvx * normal.x) + (pvy * normal.y) + (pvz * normal.z));
+			const float mult = cosv > 0 ? 1.f : -1.f;
+			tnx *= mult; tny *= mult; tnz *= mult;
+			M3 dL_dR;
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				dL_dR.m[0][r] = dM[0][r] * sc0;
+				dL_dR.m[1][r] = dM[1][r] * sc1;
+			}
+			dL_dR.m[2][0] = tnx; dL_dR.m[2][1] = tny; dL_dR.m[2][2] = tnz;
+			quat_vjp(qw, qx, qy, qz, dL_dR, drot);
+			dscale[0] = dM[0][0] * R.m[0][0] + dM[0][1] * R.m[0][1] + dM[0][2] * R.m[0][2];
+			dscale[1] = dM[1][0] * R.m[1][0] + dM[1][1] * R.m[1][1] + dM[1][2] * R.m[1][2];
+			dmean[0] = dM[2][0]; dmean[1] = dM[2][1]; dmean[2] = dM[2][2];
+		}
+		// densification signal overwrites dL_dmean2D.xy (backward.cu:656-659); it reads dL_dtransMat as stored
+		const float depth = rc[2].z;  // transMats[idx*9+8]
+		out_m2x = (float)((double)(dTout[2] * depth) * 0.5 * (double)float(Wb));
+		out_m2y = (float)((double)(dTout[5] * depth) * 0.5 * (double)float(Hb));
+	}
+	if (shs != nullptr) {
+		if (visible) {
+			ShRow s;
+			load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+			const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+			const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(gcol[0], gcol[1], gcol[2]), dL_dsh);
+			dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+		} else {
+			float* out = dL_dsh + (size_t)idx * M * 3;
+			for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+		}
+	}
+	dL_dmean2D[3 * idx] = out_m2x; dL_dmean2D[3 * idx + 1] = out_m2y; dL_dmean2D[3 * idx + 2] = 0.f;
+	dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+	for (int i = 0; i < 9; i++) dL_dtransMat[9 * idx + i] = dTout[i];
+	dL_dscale[2 * idx] = dscale[0]; dL_dscale[2 * idx + 1] = dscale[1];
+	reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+static SurfelCam make_scam(const float* view, const float* proj, const float* campos, int W, int H, float tan_fovx, float tan_fovy) {
+	SurfelCam c;
+	c.view = view; c.proj = proj; c.campos = campos; c.W = W; c.H = H;
+	c.tan_fovx = tan_fovx; c.tan_fovy = tan_fovy;
+	c.focal_y = H / (2.0f * tan_fovy);   // DSR rasterizer_impl.cu:228-229
+	c.focal_x = W / (2.0f * tan_fovx);
+	return c;
+}
+
+extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                                  const float* means3D, const uint8_t* env_scope_mask, const float* shs, const float* colors_precomp,
+                                  const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
+                                  const float* rotations, const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_others,
+                                  float* out_refl_strength_map, int* radii, float* gaussian_weights, int debug, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (!alloc || P < 0 || width <= 0 || height <= 0 || !background || !out_color || !out_others || !out_refl_strength_map) {
+		set_error("gsr_surfel_forward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	if (P == 0) {
+		GSR_HIP_CHECK(hipMemsetAsync(out_color, 0, HW * 3 * 4, stream));
+		GSR_HIP_CHECK(hipMemsetAsync(out_others, 0, HW * 8 * 4, stream));
+		GSR_HIP_CHECK(hipMemsetAsync(out_refl_strength_map, 0, HW * 4, stream));
+		return 0;
+	}
+	if (!means3D || !opacities || !refl_strengths || !viewmatrix || !projmatrix || !cam_pos || !radii || !gaussian_weights ||
+	    (!shs && !colors_precomp) || ((!scales || !rotations) && !transMat_precomp)) {
+		set_error("gsr_surfel_forward: missing required input pointer");
+		return GSR_E_INVALID;
+	}
+	if (D < 0 || D > 3 || (shs && (D + 1) * (D + 1) > M)) { set_error("gsr_surfel_forward: SH degree %d not supported with M=%d", D, M); return GSR_E_INVALID; }
+	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+	const int ntiles = tiles_x * tiles_y;
+
+	size_t geom_bytes = 0, img_bytes = 0;
+	const size_t scan_bytes = scan_temp_bytes(P);
+	carve_geom(nullptr, P, S_REC_F4, 0, S_ACC_F, scan_bytes, &geom_bytes);
+	carve_image(nullptr, HW, ntiles, 3, 2, &img_bytes);
+	void* gbuf = alloc(alloc_user, GSR_BUF_GEOM, geom_bytes);
+	void* ibuf = alloc(alloc_user, GSR_BUF_IMAGE, img_bytes);
+	if (!gbuf || !ibuf) { set_error("workspace allocation failed (%zu / %zu bytes)", geom_bytes, img_bytes); return GSR_E_ALLOC; }
+	GeomState geom = carve_geom(gbuf, P, S_REC_F4, 0, S_ACC_F, scan_bytes, nullptr);
+	ImageState img = carve_image(ibuf, HW, ntiles, 3, 2, nullptr);
+
+	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
+	GSR_HIP_CHECK(hipMemsetAsync(gaussian_weights, 0, (size_t)P * sizeof(float), stream));
+	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+	surfel_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+	                                                              transMat_precomp, colors_precomp, refl_strengths, env_scope_mask, cam, radii, geom,
+	                                                              tiles_x, tiles_y, prefiltered);
+	GSR_LAUNCH_CHECK(debug, stream);
+
+	BinningState bin;
+	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
+	if (R < 0) return R;
+
+	const int nblocks = ((ntiles + 7) / 8) * 8;
+	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+	                                                      img.final_T, img.n_contrib, out_color, out_others, out_refl_strength_map, gaussian_weights);
+	GSR_LAUNCH_CHECK(debug, stream);
+	return R;
+}
+
+extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* refl_strengths, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                                   void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                                   const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                                   float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                                   float* dL_drot, int debug, void* stream_) {
+	(void)colors_precomp; (void)refl_strengths; (void)scale_modifier; (void)transMat_precomp;
+	hipStream_t stream = (hipStream_t)stream_;
+	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_surfel_backward: invalid size"); return GSR_E_INVALID; }
+	if (P == 0) return 0;
+	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer) || !dL_dpix || !dL_dothers || !dL_drefl_strength_map || !dL_dmean2D ||
+	    !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_drefl_strengths || !dL_dmean3D || !dL_dtransMat || !dL_dscale || !dL_drot ||
+	    (shs && !dL_dsh) || !radii || !means3D) {
+		set_error("gsr_surfel_backward: missing required pointer");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)width * height;
+	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
+	const int ntiles = tiles_x * tiles_y;
+	GeomState geom = carve_geom(geom_buffer, P, S_REC_F4, 0, S_ACC_F, scan_temp_bytes(P), nullptr);
+	ImageState img = carve_image(image_buffer, HW, ntiles, 3, 2, nullptr);
+	BinningState bin = carve_binning(binning_buffer, R, 0, nullptr);
+
+	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
+	if (R > 0) {
+		const int nblocks = ((ntiles + 7) / 8) * 8;
+		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc);
+		GSR_LAUNCH_CHECK(debug, stream);
+	}
+	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+	// scales == NULL selects the transMat_precomp path in the per-surfel backward (DSR backward.cu:639)
+	surfel_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, scales, rotations, geom.rec, cam,
+	                                                                  geom.acc, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths,
+	                                                                  dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
+	GSR_LAUNCH_CHECK(debug, stream);
+	return 0;
+}

@@ -1,0 +1,108 @@
+"""Stand-in for the reference's pybind module `diff_gaussian_rasterization._C`
+(submodules/diff-gaussian-rasterization/ext.cpp:15-19) over the C ABI of libgsr_hip.so.
+
+Tensor plumbing follows RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible of
+submodules/diff-gaussian-rasterization/rasterize_points.cu:38-140, 142-264, 266-285.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _gsr  # noqa: E402
+from _gsr import check, f32c, lib, ptr, stream_ptr  # noqa: E402
+
+NUM_CHANNELS = 3
+
+
+def _dev(t, dev):
+    """The reference's Python wrapper passes CPU `torch.Tensor([])` placeholders (DGR __init__.py:198-208);
+    their data pointer is null, so only emptiness matters."""
+    return t
+
+
+def rasterize_gaussians(background, means3D, colors, normals, refl_strengths, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                        antialiasing, debug):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a CUDA tensor")
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    dev = means3D.device
+    fopts = dict(dtype=torch.float32, device=dev)
+    out_color = torch.empty((NUM_CHANNELS, H, W), **fopts)
+    out_normal_map = torch.empty((3, H, W), **fopts)
+    out_invdepth = torch.empty((1, H, W), **fopts)
+    out_refl = torch.empty((1, H, W), **fopts)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    ws = _gsr.Workspace(dev)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    keep = [f32c(background, "background"), f32c(means3D, "means3D"), f32c(sh, "sh"), f32c(colors, "colors"), f32c(normals, "normals"),
+            f32c(refl_strengths, "refl_strengths"), f32c(opacity, "opacity"), f32c(scales, "scales"), f32c(rotations, "rotations"),
+            f32c(cov3D_precomp, "cov3D_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"), f32c(campos, "campos")]
+    bg, m3, shc, col, nrm, refl, opa, sca, rot, cov, vm, pm, cp = keep
+    with torch.cuda.device(dev):
+        rendered = check(lib.gsr_gauss_forward(ws.cb, None, P, int(degree), M, ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(nrm), ptr(refl),
+                                               ptr(opa), ptr(sca), float(scale_modifier), ptr(rot), ptr(cov), ptr(vm), ptr(pm), ptr(cp),
+                                               float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), ptr(out_color), ptr(out_normal_map),
+                                               ptr(out_refl), ptr(out_invdepth), int(bool(antialiasing)), ptr(radii), int(bool(debug)),
+                                               stream_ptr(dev)), "gsr_gauss_forward")
+    if ws.error is not None:
+        raise ws.error
+    geomBuffer, binningBuffer, imgBuffer = ws.bufs
+    return rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_invdepth, out_normal_map, out_refl
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, normals, refl_strengths, opacities, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
+                                 dL_dout_normal_map, dL_dout_refl_strength_map, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                 antialiasing, debug):
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    dev = means3D.device
+    o = dict(dtype=torch.float32, device=dev)
+    mk = torch.empty if P != 0 else torch.zeros
+    dL_dmeans3D, dL_dmeans2D, dL_dmeans2D_pixels = mk((P, 3), **o), mk((P, 3), **o), mk((P, 3), **o)
+    dL_dcolors, dL_dnormals, dL_dconic = mk((P, NUM_CHANNELS), **o), mk((P, 3), **o), mk((P, 2, 2), **o)
+    dL_dopacity, dL_dcov3D, dL_dsh = mk((P, 1), **o), mk((P, 6), **o), mk((P, M, 3), **o)
+    dL_dscales, dL_drotations = mk((P, 3), **o), mk((P, 4), **o)
+    # depth / refl-strength backward are active whenever the incoming grad tensors are non-empty
+    # (DGR rasterize_points.cu:196-216)
+    has_inv = dL_dout_invdepth is not None and dL_dout_invdepth.numel() != 0
+    dL_dinvdepths = mk((P, 1), **o) if has_inv else torch.zeros((0, 1), **o)
+    has_refl = dL_dout_refl_strength_map is not None and dL_dout_refl_strength_map.numel() != 0
+    if not has_refl:
+        dL_dout_refl_strength_map = torch.zeros((1, H, W), **o)
+    dL_drefl = mk((P, 1), **o)
+    if P != 0:
+        keep = [f32c(background, "background"), f32c(means3D, "means3D"), f32c(sh, "sh"), f32c(colors, "colors"), f32c(normals, "normals"),
+                f32c(refl_strengths, "refl_strengths"), f32c(opacities, "opacities"), f32c(scales, "scales"), f32c(rotations, "rotations"),
+                f32c(cov3D_precomp, "cov3D_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"), f32c(campos, "campos"),
+                f32c(dL_dout_color, "dL_dout_color"), f32c(dL_dout_normal_map, "dL_dout_normal_map"),
+                f32c(dL_dout_refl_strength_map, "dL_dout_refl_strength_map"),
+                f32c(dL_dout_invdepth, "dL_dout_invdepth") if has_inv else None, radii.contiguous()]
+        bg, m3, shc, col, nrm, refl, opa, sca, rot, cov, vm, pm, cp, gcol, gnrm, grefl, ginv, rad = keep
+        with torch.cuda.device(dev):
+            check(lib.gsr_gauss_backward(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(nrm), ptr(refl), ptr(opa),
+                                         ptr(sca), float(scale_modifier), ptr(rot), ptr(cov), ptr(vm), ptr(pm), ptr(cp), float(tan_fovx),
+                                         float(tan_fovy), ptr(rad), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), ptr(gcol), ptr(gnrm),
+                                         ptr(grefl), ptr(ginv), ptr(dL_dmeans2D), ptr(dL_dmeans2D_pixels), ptr(dL_dconic), ptr(dL_dopacity),
+                                         ptr(dL_dcolors), ptr(dL_dnormals), ptr(dL_drefl), ptr(dL_dinvdepths), ptr(dL_dmeans3D),
+                                         ptr(dL_dcov3D), ptr(dL_dsh), ptr(dL_dscales), ptr(dL_drotations), int(bool(antialiasing)),
+                                         int(bool(debug)), stream_ptr(dev)), "gsr_gauss_backward")
+    if not has_refl:
+        dL_drefl = torch.zeros((0, 1), **o)
+    return (dL_dmeans2D_pixels, dL_dcolors, dL_dnormals, dL_drefl, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m3, vm, pm = f32c(means3D, "means3D"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            check(lib.gsr_mark_visible(P, ptr(m3), ptr(vm), ptr(pm), ptr(present), stream_ptr(means3D.device)), "gsr_mark_visible")
+    return present

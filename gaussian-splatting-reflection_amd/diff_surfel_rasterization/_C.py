@@ -1,0 +1,105 @@
+"""Stand-in for the reference's pybind module `diff_surfel_rasterization._C`
+(submodules/diff-surfel-rasterization/ext.cpp:15-19): the same three functions with the same
+positional arguments and return tuples, implemented over the C ABI of libgsr_hip.so.
+
+Tensor plumbing follows RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible of
+submodules/diff-surfel-rasterization/rasterize_points.cu:39-151, 153-267, 269-288.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _gsr  # noqa: E402
+from _gsr import check, f32c, lib, ptr, require_cuda, stream_ptr  # noqa: E402
+
+NUM_CHANNELS = 3
+
+
+def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations, scale_modifier,
+                        transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("refl_strengths", refl_strengths),
+                    ("opacity", opacity), ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos)):
+        require_cuda(t, name)
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    dev = means3D.device
+    fopts = dict(dtype=torch.float32, device=dev)
+    out_color = torch.empty((NUM_CHANNELS, H, W), **fopts)
+    out_others = torch.empty((3 + 3 + 1 + 1, H, W), **fopts)
+    out_refl = torch.empty((1, H, W), **fopts)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    gaussian_weights = torch.empty((P,), **fopts)
+    ws = _gsr.Workspace(dev)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    mask = env_scope_mask
+    if mask is not None and mask.numel() != 0:
+        if mask.dtype != torch.bool:
+            raise RuntimeError(f"expected scalar type Bool but found {mask.dtype} for env_scope_mask")
+        mask = mask.contiguous()
+    keep = [f32c(background, "background"), f32c(means3D, "means3D"), f32c(sh, "sh"), f32c(colors, "colors"),
+            f32c(refl_strengths, "refl_strengths"), f32c(opacity, "opacity"), f32c(scales, "scales"), f32c(rotations, "rotations"),
+            f32c(transMat_precomp, "transMat_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"),
+            f32c(campos, "campos")]
+    bg, m3, shc, col, refl, opa, sca, rot, tmp, vm, pm, cp = keep
+    with torch.cuda.device(dev):
+        rendered = check(lib.gsr_surfel_forward(ws.cb, None, P, int(degree), M, ptr(bg), W, H, ptr(m3), ptr(mask), ptr(shc), ptr(col),
+                                                ptr(refl), ptr(opa), ptr(sca), float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm),
+                                                ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), ptr(out_color),
+                                                ptr(out_others), ptr(out_refl), ptr(radii), ptr(gaussian_weights), int(bool(debug)),
+                                                stream_ptr(dev)), "gsr_surfel_forward")
+    if ws.error is not None:
+        raise ws.error
+    geomBuffer, binningBuffer, imgBuffer = ws.bufs
+    return rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer, out_refl, gaussian_weights
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, dL_dout_refl_strength_map, sh,
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors), ("scales", scales),
+                    ("rotations", rotations), ("transMat_precomp", transMat_precomp), ("viewmatrix", viewmatrix),
+                    ("projmatrix", projmatrix), ("sh", sh), ("campos", campos), ("binningBuffer", binningBuffer),
+                    ("imageBuffer", imageBuffer), ("geomBuffer", geomBuffer)):
+        require_cuda(t, name)
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    dev = means3D.device
+    o = dict(dtype=torch.float32, device=dev)
+    # the library writes every element, so no zero-fill is needed (the reference uses torch::zeros)
+    mk = torch.empty if P != 0 else torch.zeros
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = mk((P, 3), **o), mk((P, 3), **o), mk((P, NUM_CHANNELS), **o), mk((P, 3), **o)
+    dL_dopacity, dL_dtransMat, dL_dsh = mk((P, 1), **o), mk((P, 9), **o), mk((P, M, 3), **o)
+    dL_dscales, dL_drotations, dL_drefl = mk((P, 2), **o), mk((P, 4), **o), mk((P, 1), **o)
+    if dL_dout_refl_strength_map is None or dL_dout_refl_strength_map.numel() == 0:
+        dL_dout_refl_strength_map = torch.zeros((1, H, W), **o)
+    if P != 0:
+        keep = [f32c(background, "background"), f32c(means3D, "means3D"), f32c(sh, "sh"), f32c(colors, "colors"),
+                f32c(refl_strengths, "refl_strengths"), f32c(scales, "scales"), f32c(rotations, "rotations"),
+                f32c(transMat_precomp, "transMat_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"),
+                f32c(campos, "campos"), f32c(dL_dout_color, "dL_dout_color"), f32c(dL_dout_others, "dL_dout_others"),
+                f32c(dL_dout_refl_strength_map, "dL_dout_refl_strength_map"), radii.contiguous()]
+        bg, m3, shc, col, refl, sca, rot, tmp, vm, pm, cp, gcol, goth, grefl, rad = keep
+        with torch.cuda.device(dev):
+            check(lib.gsr_surfel_backward(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
+                                          float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm), ptr(cp), float(tan_fovx),
+                                          float(tan_fovy), ptr(rad), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), ptr(gcol),
+                                          ptr(goth), ptr(grefl), ptr(dL_dmeans2D), ptr(dL_dnormal), ptr(dL_dopacity), ptr(dL_dcolors),
+                                          ptr(dL_drefl), ptr(dL_dmeans3D), ptr(dL_dtransMat), ptr(dL_dsh), ptr(dL_dscales),
+                                          ptr(dL_drotations), int(bool(debug)), stream_ptr(dev)), "gsr_surfel_backward")
+    return dL_dmeans2D, dL_dcolors, dL_drefl, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m3, vm, pm = f32c(means3D, "means3D"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            check(lib.gsr_mark_visible(P, ptr(m3), ptr(vm), ptr(pm), ptr(present), stream_ptr(means3D.device)), "gsr_mark_visible")
+    return present

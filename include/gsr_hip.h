@@ -1,0 +1,163 @@
+/*
+ * gsr_hip.h — C ABI of libgsr_hip.so, the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary below the reference's PyTorch extension modules.  Every entry
+ * point takes plain device pointers, sizes and a hipStream_t (passed as void*); there are no
+ * torch types.  All device pointers must be valid on the current HIP device; "may be NULL"
+ * is stated per argument.  All arithmetic is fp32; integer outputs are int32/uint32/uint8.
+ *
+ * Reference interfaces replaced (paths relative to the reference repository):
+ *   DSR = submodules/diff-surfel-rasterization, DGR = submodules/diff-gaussian-rasterization,
+ *   CME = submodules/cubemapencoder.
+ *
+ * Return convention: >= 0 success (forward entry points return num_rendered), < 0 error code
+ * (GSR_E_*); gsr_last_error() returns a thread-local description of the last failure.
+ *
+ * Workspace protocol: the three opaque per-call buffers the reference grows through
+ * std::function<char*(size_t)> callbacks (DSR rasterize_points.cu:31-37, rasterizer.h:27-29)
+ * are requested through `gsr_alloc_fn`: it is called at most once per `which` per forward
+ * call with the exact byte size and must return a device pointer aligned to >= 256 bytes that
+ * stays valid until the matching backward call has completed.  The layout inside the buffers
+ * is private to this library and differs from the reference's.
+ */
+#ifndef GSR_HIP_H_
+#define GSR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_BUF_GEOM 0
+#define GSR_BUF_BINNING 1
+#define GSR_BUF_IMAGE 2
+
+#define GSR_E_INVALID (-1)     /* bad argument (NULL where required, negative size) */
+#define GSR_E_HIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define GSR_E_ALLOC (-3)       /* gsr_alloc_fn returned NULL */
+#define GSR_E_PREFILTERED (-4) /* a Gaussian was culled although prefiltered was set (reference: __trap()) */
+#define GSR_E_NONRGB (-5)      /* NUM_CHANNELS != 3 without precomputed colours (never: library is built for 3) */
+
+typedef void* (*gsr_alloc_fn)(void* user, int which, size_t bytes);
+
+const char* gsr_last_error(void);
+int gsr_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Variant S — 2D Gaussian surfels.  Replaces CudaRasterizer::Rasterizer::forward
+ * (DSR cuda_rasterizer/rasterizer.h:24-56, rasterizer_impl.cu:198-355).
+ *   env_scope_mask  uint8[P] (bool) or NULL (= all false)
+ *   shs             float[P,M,3] or NULL when colors_precomp is given
+ *   scales float[P,2], rotations float[P,4] or NULL when transMat_precomp float[P,9] is given
+ *   out_color float[3,H,W]; out_others float[8,H,W]; out_refl_strength_map float[H,W];
+ *   radii int32[P]; gaussian_weights float[P].  All outputs are fully written.
+ * Returns num_rendered. */
+int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width,
+                       int height, const float* means3D, const uint8_t* env_scope_mask, const float* shs,
+                       const float* colors_precomp, const float* refl_strengths, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, float* out_color, float* out_others,
+                       float* out_refl_strength_map, int* radii, float* gaussian_weights, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (DSR rasterizer.h:58-95, rasterizer_impl.cu:358-466).
+ *   R = num_rendered returned by the forward call; geom/binning/image = the forward's buffers.
+ *   dL_dpix float[3,H,W]; dL_dothers float[8,H,W] (planes 0-6 read); dL_drefl_strength_map float[H,W]
+ *   Outputs (fully written, no pre-zeroing needed): dL_dmean2D[P,3] dL_dnormal[P,3] dL_dopacity[P]
+ *   dL_dcolor[P,3] dL_drefl_strengths[P] dL_dmean3D[P,3] dL_dtransMat[P,9] dL_dsh[P,M,3]
+ *   dL_dscale[P,2] dL_drot[P,4]. */
+int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* refl_strengths, const float* scales, float scale_modifier, const float* rotations,
+                        const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                        void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                        const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                        float* dL_dcolor, float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat,
+                        float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Variant G — 3D Gaussians with EWA projection, anti-aliasing and inverse depth.  Replaces
+ * CudaRasterizer::Rasterizer::forward (DGR cuda_rasterizer/rasterizer.h:24-57, rasterizer_impl.cu:198-349).
+ *   normals float[P,3], refl_strengths float[P] are required.
+ *   out_color[3,H,W] out_normal_map[3,H,W] out_refl_strength_map[H,W] out_invdepth[H,W] or NULL, radii int32[P]. */
+int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width,
+                      int height, const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* normals, const float* refl_strengths, const float* opacities, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                      const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                      float* out_color, float* out_normal_map, float* out_refl_strength_map, float* out_invdepth,
+                      int antialiasing, int* radii, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (DGR rasterizer.h:59-101, rasterizer_impl.cu:353-472).
+ *   dL_invdepths may be NULL (then dL_dinvdepth is not touched).  dL_dmean2D_pixels is what the
+ *   reference hands to Python as grad_means2D (DGR rasterize_points.cu:263).  dL_dconic is float[P,4]
+ *   (slots x,y,w used).  Outputs are fully written. */
+int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* normals,
+                       const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                       void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix,
+                       const float* dL_dnormal_map, const float* dL_drefl_strength_map, const float* dL_invdepths,
+                       float* dL_dmean2D, float* dL_dmean2D_pixels, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                       int antialiasing, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (DSR rasterizer.h:19-23, rasterizer_impl.cu:141-153). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Introspection of the private workspace (used by the parity tests; a maintainer never needs it).
+ * Copies the named per-Gaussian / per-instance / per-pixel array from the workspaces of a
+ * completed forward call into `dst` (device pointer).  variant: 0 = S, 1 = G.
+ * Names: "depths" f32[P], "means2D" f32[P,2], "tiles_touched" u32[P], "point_offsets" u32[P],
+ * "clamped" u8[P,3], "rgb" f32[P,3], "geom4" f32[P,4] (conic_opacity / normal_opacity),
+ * "transMat" f32[P,9] (S), "cov3D" f32[P,6] (G), "point_list" u32[R], "keys" u64[R],
+ * "ranges" u32[tiles,2], "final_T" f32[planes,H,W], "n_contrib" u32[planes,H,W]. */
+int gsr_debug_fetch(int variant, const char* name, int P, int R, int width, int height, const void* geom_buffer,
+                    const void* binning_buffer, const void* image_buffer, void* dst, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cubemap encoder.  Replaces cubemap_encode_forward / cubemap_encode_backward
+ * (CME src/cubemapencoder.h:6-17, cubemapencoder.cu:430-488, 713-779).  fp32 only.
+ *   inputs float[B,3]; cubemap float[6,C,L,L]; fail_value float[C]; outputs float[C,B] (channel-major).
+ *   interp: 0 nearest, 1 bilinear; seamless: 0/1. */
+int gsr_cubemap_forward(const float* inputs, const float* cubemap, const float* fail_value, float* outputs,
+                        uint32_t interp, uint32_t seamless, uint32_t B, uint32_t C, uint32_t L, void* stream);
+/*   grad_cubemap [6,C,L,L] and grad_fail [C] are accumulated into (the caller zeroes them, as
+ *   cubemap_encoder.py:53-55 does); grad_inputs [B,3] is fully written. */
+int gsr_cubemap_backward(const float* grad_outputs, const float* inputs, const float* cubemap, float* grad_cubemap,
+                         float* grad_inputs, float* grad_fail, uint32_t interp, uint32_t seamless, uint32_t B,
+                         uint32_t C, uint32_t L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused deferred-reflection pixel pass.  Replaces the ~12 torch ops of
+ * gaussian_renderer/__init__.py:22-35,148,178-179,197-199 + utils/general_utils.py:177-197:
+ *   n_world = normalize(N_view . W2V[:3,:3]^T) (+1e-6), d = normalize((K^-1 [x,y,1] - T) . R^T ... ),
+ *   r = d - 2 n (d.n), c = sigmoid(cubemap(r)), final = (1-s) base + s c.
+ *   normal_view float[3,H,W] (allmap planes 2..4); base_color float[3,H,W]; refl_strength float[H,W];
+ *   cam: float[25] = viewmatrix 3x3 block (row-major, 9) | Kinv (9, row-major) | R_w2c (9, row-major) | T (3) |
+ *   campos filled by the host (see host code); outputs final float[3,H,W], refl_color float[3,H,W],
+ *   normal_world float[3,H,W] (normalised). C must be 3. */
+int gsr_deferred_reflection_forward(const float* normal_view, const float* base_color, const float* refl_strength,
+                                    const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
+                                    int width, int height, float* out_final, float* out_refl_color,
+                                    float* out_normal_world, void* stream);
+/*   Upstream grads: g_final [3,H,W] (required), g_refl_color, g_normal_world may be NULL.
+ *   Outputs: g_normal_view [3,H,W], g_base [3,H,W], g_strength [H,W] fully written; g_cubemap,
+ *   g_fail accumulated into. */
+int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength,
+                                     const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
+                                     int width, int height, const float* g_final, const float* g_refl_color,
+                                     const float* g_normal_world, float* g_normal_view, float* g_base,
+                                     float* g_strength, float* g_cubemap, float* g_fail, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_HIP_H_ */

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gaussian-splatting-reflection_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib_built():
+    """Make sure libgsr_hip.so exists (hipcc cross-compiles without a GPU)."""
+    sys.path.insert(0, os.path.join(PKG, "csrc"))
+    import build as gsr_build
+    return gsr_build.build()
