@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: one "step" = forward + backward of the hot path for one 1080p view of 1e6
+Gaussians (BASELINE config C3): surfel rasterizer (variant S, the one gaussian_renderer calls) +
+fused deferred reflection / cubemap lookup, then their backward with synthetic upstream gradients.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own view of the same
+1e6-Gaussian scene (weak scaling: per-GPU work fixed) and the per-Gaussian + cubemap gradients are summed
+with ONE RCCL all-reduce over a flat pre-packed buffer.  value = views/s over all ranks.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (tile-render backward): algorithmic bytes / hipEvent-measured launch time
+  cpu_baseline  the CPU oracle (oracle/, "port") timed on this host on one full C3 step
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gaussian-splatting-reflection_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def yaw_camera(S, W, H, deg):
+    """Base C3 camera (R = I, T = 0) rotated about the y axis by `deg` degrees: rank r looks r*3 degrees to the side."""
+    a = math.radians(deg)
+    c2w = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=np.float64)
+    return S.make_camera(W, H, R=c2w, T=np.zeros(3))
+
+
+class Scene:
+    """Parameters of the synthetic scene as leaf tensors whose .grad are views into ONE flat buffer
+    (the all-reduce payload: 59 floats per Gaussian + cubemap texels + fail value)."""
+
+    def __init__(self, S, P, mu, L, device, seed):
+        sc = S.make_scene(P, "S", seed=seed, mu=mu)
+        tex, fail = S.make_cubemap(L, 3, seed)
+        names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
+        src = {k: torch.from_numpy(sc[k]) for k in names}
+        src["cubemap"] = torch.from_numpy(tex)
+        src["fail"] = torch.from_numpy(fail)
+        total = sum(v.numel() for v in src.values())
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.p = {}
+        off = 0
+        for k, v in src.items():
+            t = v.to(device).requires_grad_(True)
+            t.grad = self.flat_grad[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+            self.p[k] = t
+        self.mask = torch.from_numpy(sc["env_scope_mask"]).to(device)
+        self.P = P
+
+
+class EnvMap:
+    def __init__(self, tex, fail):
+        self.params = {"Cubemap_texture": tex, "Cubemap_failv": fail}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--mu", type=float, default=-4.75)
+    ap.add_argument("--cubemap", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    import gsr_synth as S
+    import _gsr
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussian_renderer import deferred_reflection
+
+    P, W, H = args.gaussians, args.width, args.height
+    scene = Scene(S, P, args.mu, args.cubemap, dev, seed=1003)
+    cam = yaw_camera(S, W, H, 3.0 * rank)
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
+    bg = torch.zeros(3, device=dev)
+    settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg,
+                                             scale_modifier=1.0, viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"], sh_degree=3,
+                                             campos=ct["campos"], prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(settings)
+    env = EnvMap(scene.p["cubemap"], scene.p["fail"])
+    HWK = (H, W, cam["K"])
+    g = S.make_upstream_grads(H, W, 1003)
+    g_final = torch.from_numpy(g["dL_dcolor"]).to(dev)
+    g_allmap = torch.from_numpy(g["dL_dplanes"]).to(dev)
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    info = {}
+
+    def forward():
+        base, radii, allmap, refl_map, gw = rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
+                                                       shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
+                                                       scales=scene.p["scales"], rotations=scene.p["rotations"],
+                                                       env_scope_mask=scene.mask)
+        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], HWK, ct["R"], ct["T"])
+        info["R"] = base.grad_fn.num_rendered
+        return final, allmap
+
+    def step():
+        scene.flat_grad.zero_()
+        means2D.grad = None
+        final, allmap = forward()
+        torch.autograd.backward([final, allmap], [g_final, g_allmap])
+        if dist_on:
+            dist.all_reduce(scene.flat_grad)
+
+    def sync_all():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    _gsr.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    stages = _gsr.profile_collect()
+    _gsr.profile_enable(False)
+
+    # forward-only render rate (render FPS @1080p), un-timed for the headline but reported
+    with torch.no_grad():
+        for _ in range(2):
+            forward()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nf = max(5, args.steps)
+        for _ in range(nf):
+            forward()
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+
+    if dist_on:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    if rank == 0:
+        R = info["R"]
+        HW = W * H
+        bwd_ms, bwd_n = stages["render_bwd"]
+        # algorithmic bytes of ONE tile-render-backward launch (DESIGN.md §"Kernels"): per instance the 4-byte id, the
+        # 80-byte render record and one 76-byte reduced gradient row; per pixel 64 bytes of upstream grads + saved state
+        bytes_bwd = R * (4 + 80 + 76) + HW * 64
+        achieved = bytes_bwd / (bwd_ms / max(1, bwd_n) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        fwd_bytes = 347 * P + 257 * R + 68 * HW     # SURVEY.md §8d, variant S
+        bwdall_bytes = 871 * P + 156 * R + 64 * HW
+        refl_bytes = (64 + 112) * HW
+        out = {
+            "metric": "train_step_views_per_s (fwd+bwd, 1e6 Gaussians @1080p, surfel rasterizer + reflection path)",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C3: 1M Gaussians, 1920x1080, SH deg 3 + reflection/specular path (cubemap L=%d), fwd+bwd" % args.cubemap,
+                       "gaussians": P, "width": W, "height": H, "num_rendered": R, "views_per_step_per_gpu": 1,
+                       "parallelism": "1 view per GPU + RCCL all-reduce of per-Gaussian grads" if dist_on else "single GPU"},
+            "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4),
+            "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stages.items() if v[1] > 0},
+            "step_algorithmic_GBps": round((fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+            "roofline": {"kernel": "surfel_render_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(bwd_ms / max(1, bwd_n), 4), "algorithmic_bytes_per_launch": bytes_bwd},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(S, P, W, H, args.mu, args.cubemap)
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(S, P, W, H, mu, L):
+    """The CPU oracle (test infrastructure, oracle/) timed on this host: ONE full step of the same workload
+    (rasterizer fwd+bwd + cubemap lookup fwd+bwd), OpenMP over all host cores."""
+    from oracle import oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import scene_kwargs
+    kw, cam, sc = scene_kwargs("S", P, W, H, 1003, mu, 3, (0, 0, 0))
+    g = S.make_upstream_grads(H, W, 1003)
+    tex, fail = S.make_cubemap(L, 3, 1003)
+    o = orc.SurfelOracle(np.float32)
+    o.forward(**dict(kw, means3D=kw["means3D"][:1000], opacities=kw["opacities"][:1000], shs=kw["shs"][:1000],
+                     refl_strengths=kw["refl_strengths"][:1000], scales=kw["scales"][:1000], rotations=kw["rotations"][:1000],
+                     env_scope_mask=kw["env_scope_mask"][:1000]))  # warm the library
+    t = time.perf_counter()
+    ref = o.forward(**kw)
+    dirs = np.ascontiguousarray(np.moveaxis(ref["allmap"][2:5], 0, -1).reshape(-1, 3))
+    c = orc.cubemap_forward(dirs, tex, fail)
+    orc.cubemap_backward(np.ascontiguousarray(np.broadcast_to(g["dL_dcolor"].reshape(3, -1), c.shape)), dirs, tex)
+    o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
+    dt = time.perf_counter() - t
+    return {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "one full C3 step (1M Gaussians, 1920x1080, R=%d) through the CPU oracle (OpenMP, all host cores), %.1f s" % (
+                ref["num_rendered"], dt)}
+
+
+if __name__ == "__main__":
+    main()

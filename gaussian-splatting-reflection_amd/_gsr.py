@@ -56,6 +56,10 @@ def _load():
     lib.gsr_deferred_reflection_forward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P]
     lib.gsr_deferred_reflection_backward.restype = c_int
     lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P]
+    lib.gsr_profile_enable.restype = c_int
+    lib.gsr_profile_enable.argtypes = [c_int]
+    lib.gsr_profile_collect.restype = c_int
+    lib.gsr_profile_collect.argtypes = [P, P]
     return lib
 
 
@@ -63,7 +67,22 @@ lib = _load()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_backward"]
+            "gsr_deferred_reflection_backward", "gsr_profile_enable", "gsr_profile_collect"]
+
+STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",
+          "refl_bwd", "cubemap_fwd", "cubemap_bwd"]
+
+
+def profile_enable(on=True):
+    lib.gsr_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """Returns {stage: (total_ms, launches)} measured with hipEvents on the launch stream since the last call."""
+    ms = (ctypes.c_float * len(STAGES))()
+    n = (ctypes.c_int * len(STAGES))()
+    lib.gsr_profile_collect(ctypes.cast(ms, c_void_p), ctypes.cast(n, c_void_p))
+    return {STAGES[i]: (float(ms[i]), int(n[i])) for i in range(len(STAGES))}
 
 
 def check(rc, what):

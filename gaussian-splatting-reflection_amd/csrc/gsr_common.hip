@@ -5,6 +5,8 @@
 #include "gsr_internal.hpp"
 #include <cstdarg>
 #include <string>
+#include <vector>
+#include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -16,6 +18,40 @@ void set_error(const char* fmt, ...) {
 	va_start(ap, fmt);
 	vsnprintf(g_err, sizeof(g_err), fmt, ap);
 	va_end(ap);
+}
+
+
+// ---------------------------------------------------------------- per-stage timing
+struct ProfRec {
+	int stage;
+	hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec*> g_prof_recs;
+static std::vector<ProfRec*> g_prof_free;
+static std::mutex g_prof_mu;
+
+StageTimer::StageTimer(int stage_, hipStream_t stream_) : stage(stage_), stream(stream_), rec(nullptr) {
+	if (!g_prof_on) return;
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	ProfRec* r = nullptr;
+	if (!g_prof_free.empty()) {
+		r = g_prof_free.back();
+		g_prof_free.pop_back();
+	} else {
+		r = new ProfRec();
+		if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) { delete r; return; }
+	}
+	r->stage = stage;
+	(void)hipEventRecord(r->e0, stream);
+	rec = r;
+}
+StageTimer::~StageTimer() {
+	if (!rec) return;
+	ProfRec* r = (ProfRec*)rec;
+	(void)hipEventRecord(r->e1, stream);
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	g_prof_recs.push_back(r);
 }
 
 // getHigherMsb (DSR/DGR rasterizer_impl.cu:35-50)
@@ -132,14 +168,17 @@ static int* pinned_word() {
 
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom, const ImageState& img,
                 BinningState* out_binning, int debug, hipStream_t stream) {
-	size_t tmp = geom.scan_temp_bytes;
-	GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, geom.tiles_touched, geom.point_offsets, (size_t)P, rocprim::plus<uint32_t>(),
-	                                      stream, false));
-	if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
 	int* host = pinned_word();
 	if (!host) { set_error("hipHostMalloc for the num_rendered readback failed"); return GSR_E_HIP; }
-	GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-	GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+	{
+		StageTimer st_(GSR_STAGE_SCAN, stream);
+		size_t tmp = geom.scan_temp_bytes;
+		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, geom.tiles_touched, geom.point_offsets, (size_t)P, rocprim::plus<uint32_t>(),
+		                                      stream, false));
+		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
+		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+		GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+	}
 	GSR_HIP_CHECK(hipStreamSynchronize(stream));
 	const int R = host[0];
 	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
@@ -157,14 +196,17 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 
 	GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));
 	if (R > 0) {
+		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		emit_keys_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.rect, geom.depths, geom.point_offsets, geom.tiles_touched, b.keys_unsorted,
-		                                                      b.vals_unsorted, (uint32_t)tiles_x);
+		                                                      b.vals_unsorted, (uint32_t)tiles_x); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
+		{ StageTimer st_(GSR_STAGE_SORT, stream);
 		GSR_HIP_CHECK(rocprim::radix_sort_pairs(b.sort_temp, sb, b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list, (size_t)R, 0u,
-		                                        (unsigned)(32 + bit), stream, false));
+		                                        (unsigned)(32 + bit), stream, false)); }
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
-		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.keys, img.ranges);
+		{ StageTimer st_(GSR_STAGE_RANGES, stream);
+		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.keys, img.ranges); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	return R;
@@ -203,6 +245,29 @@ using namespace gsr;
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
 extern "C" int gsr_version(void) { return 100; }
+
+
+extern "C" int gsr_profile_enable(int on) {
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	for (ProfRec* r : g_prof_recs) g_prof_free.push_back(r);
+	g_prof_recs.clear();
+	g_prof_on = on != 0;
+	return 0;
+}
+extern "C" int gsr_profile_collect(float* ms_out, int* launches_out) {
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	for (int i = 0; i < GSR_STAGE_COUNT; i++) { if (ms_out) ms_out[i] = 0.f; if (launches_out) launches_out[i] = 0; }
+	for (ProfRec* r : g_prof_recs) {
+		float ms = 0.f;
+		if (hipEventSynchronize(r->e1) == hipSuccess && hipEventElapsedTime(&ms, r->e0, r->e1) == hipSuccess) {
+			if (ms_out) ms_out[r->stage] += ms;
+			if (launches_out) launches_out[r->stage] += 1;
+		}
+		g_prof_free.push_back(r);
+	}
+	g_prof_recs.clear();
+	return 0;
+}
 
 extern "C" int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                                 void* stream_) {

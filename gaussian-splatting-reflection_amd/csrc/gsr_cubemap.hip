@@ -439,7 +439,7 @@ extern "C" int gsr_cubemap_forward(const float* inputs, const float* cubemap, co
 	hipStream_t stream = (hipStream_t)stream_;
 	if (B == 0) return 0;
 	if (!inputs || !cubemap || !fail_value || !outputs || C == 0 || L == 0) { set_error("gsr_cubemap_forward: invalid argument"); return GSR_E_INVALID; }
-	cubemap_fwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(inputs, cubemap, fail_value, outputs, (int)interp, (int)seamless, B, (int)C, (int)L);
+{ StageTimer st_(GSR_STAGE_CUBEMAP_FWD, stream); 	cubemap_fwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(inputs, cubemap, fail_value, outputs, (int)interp, (int)seamless, B, (int)C, (int)L); }
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }
@@ -453,8 +453,8 @@ extern "C" int gsr_cubemap_backward(const float* grad_outputs, const float* inpu
 		set_error("gsr_cubemap_backward: invalid argument");
 		return GSR_E_INVALID;
 	}
-	cubemap_bwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(grad_outputs, inputs, cubemap, grad_cubemap, grad_inputs, grad_fail, (int)interp,
-	                                                        (int)seamless, B, (int)C, (int)L);
+{ StageTimer st_(GSR_STAGE_CUBEMAP_BWD, stream); 	cubemap_bwd_kernel<<<(B + 255) / 256, 256, 0, stream>>>(grad_outputs, inputs, cubemap, grad_cubemap, grad_inputs, grad_fail, (int)interp,
+	                                                        (int)seamless, B, (int)C, (int)L); }
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }
@@ -469,8 +469,8 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
-	deferred_refl_fwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
-	                                                                         (int)L, width, height, out_final, out_refl_color, out_normal_world);
+{ StageTimer st_(GSR_STAGE_REFL_FWD, stream); 	deferred_refl_fwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+	                                                                         (int)L, width, height, out_final, out_refl_color, out_normal_world); }
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }
@@ -487,9 +487,9 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
-	deferred_refl_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+{ StageTimer st_(GSR_STAGE_REFL_BWD, stream); 	deferred_refl_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
 	                                                                         (int)L, width, height, g_final, g_refl_color, g_normal_world,
-	                                                                         g_normal_view, g_base, g_strength, g_cubemap, g_fail);
+	                                                                         g_normal_view, g_base, g_strength, g_cubemap, g_fail); }
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }

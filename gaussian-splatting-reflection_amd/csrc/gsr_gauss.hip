@@ -645,9 +645,9 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
-	gauss_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+{ StageTimer st_(GSR_STAGE_PREPROCESS, stream); 	gauss_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
 	                                                             colors_precomp, normals, refl_strengths, cam, radii, geom, tiles_x, tiles_y,
-	                                                             prefiltered, antialiasing);
+	                                                             prefiltered, antialiasing); }
 	GSR_LAUNCH_CHECK(debug, stream);
 
 	BinningState bin;
@@ -656,13 +656,13 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 
 	const int nblocks = ((ntiles + 7) / 8) * 8;
 	if (out_invdepth)
-		gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
 		                                                          img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
-		                                                          out_invdepth);
+		                                                          out_invdepth); }
 	else
-		gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
 		                                                           img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
-		                                                           nullptr);
+		                                                           nullptr); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
 }
@@ -697,22 +697,22 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 	if (R > 0) {
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 		if (dL_invdepths)
-			gauss_render_bwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 			                                                          img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
-			                                                          dL_invdepths, geom.acc);
+			                                                          dL_invdepths, geom.acc); }
 		else
-			gauss_render_bwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 			                                                           img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
-			                                                           nullptr, geom.acc);
+			                                                           nullptr, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 	const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : geom.aux;
-	gauss_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,
+{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream); 	gauss_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,
 	                                                                 scale_modifier, cov3D_ptr, cam, geom.acc, dL_invdepths ? 1 : 0, antialiasing,
 	                                                                 dL_dmean2D, dL_dmean2D_pixels, dL_dconic, dL_dopacity, dL_dcolor, dL_dnormals,
 	                                                                 dL_drefl_strengths, dL_dinvdepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-	                                                                 dL_drot);
+	                                                                 dL_drot); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return 0;
 }

@@ -30,6 +30,17 @@ void set_error(const char* fmt, ...);
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));          \
 	} while (0)
 
+// ------------------------------------------------------------------ per-stage timing (off by default)
+// RAII: records a start event at construction and a stop event at destruction on `stream` when profiling
+// is enabled (gsr_profile_enable); a no-op otherwise.
+struct StageTimer {
+	int stage;
+	hipStream_t stream;
+	void* rec;
+	StageTimer(int stage, hipStream_t stream);
+	~StageTimer();
+};
+
 // ------------------------------------------------------------------ workspace carving
 // Bump allocation with 256-byte alignment inside the three opaque buffers (the reference's
 // obtain()/required(), DSR rasterizer_impl.h:21-73, with a private layout).

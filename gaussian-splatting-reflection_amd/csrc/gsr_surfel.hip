@@ -184,11 +184,14 @@ template <bool FWD>
 __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, const float4 r2, float opac, float pixx, float pixy, SurfelPair& o) {
 #pragma clang fp contract(off)
 	const float Tux = r0.z, Tuy = r0.w, Tuz = r1.x, Tvx = r1.y, Tvy = r1.z, Tvz = r1.w, Twx = r2.x, Twy = r2.y, Twz = r2.z;
-	o.kx = fmaf(pixx, Twx, -Tux); o.ky = fmaf(pixx, Twy, -Tuy); o.kz = fmaf(pixx, Twz, -Tuz);
-	o.lx = fmaf(pixy, Twx, -Tvx); o.ly = fmaf(pixy, Twy, -Tvy); o.lz = fmaf(pixy, Twz, -Tvz);
-	const float ppx = fmaf(o.ky, o.lz, -(o.kz * o.ly));
-	const float ppy = fmaf(o.kz, o.lx, -(o.kx * o.lz));
-	o.pz = fmaf(o.kx, o.ly, -(o.ky * o.lx));
+	// Plain IEEE mul/sub in the reference's textual order (contraction off): the plane/plane cross product
+	// cancels catastrophically in fp32 (|k|,|l| ~ pixel coordinate x T), so evaluation order changes s by
+	// ~1e-4 relative.  Matching the order makes the HIP path agree with the oracle to rounding of exp().
+	o.kx = pixx * Twx - Tux; o.ky = pixx * Twy - Tuy; o.kz = pixx * Twz - Tuz;
+	o.lx = pixy * Twx - Tvx; o.ly = pixy * Twy - Tvy; o.lz = pixy * Twz - Tvz;
+	const float ppx = o.ky * o.lz - o.kz * o.ly;
+	const float ppy = o.kz * o.lx - o.kx * o.lz;
+	o.pz = o.kx * o.ly - o.ky * o.lx;
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
 	if (!unstable) {
 		const float inv_pz = 1.0f / o.pz;
@@ -198,12 +201,12 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 		o.sx = 0.f;
 		o.sy = 0.f;
 	}
-	o.rho3d = unstable ? 1e8f : fmaf(o.sx, o.sx, o.sy * o.sy);
+	o.rho3d = unstable ? 1e8f : (o.sx * o.sx + o.sy * o.sy);
 	o.dx = r0.x - pixx;
 	o.dy = r0.y - pixy;
-	o.rho2d = S_FILTER_INV_SQ * fmaf(o.dx, o.dx, o.dy * o.dy);
+	o.rho2d = S_FILTER_INV_SQ * (o.dx * o.dx + o.dy * o.dy);
 	const float rho = fminf(o.rho3d, o.rho2d);
-	o.depth = fmaf(o.sx, Twx, o.sy * Twy) + Twz;
+	o.depth = (o.sx * Twx + o.sy * Twy) + Twz;
 	if (o.depth < S_NEAR) return false;
 	const float power = -0.5f * rho;
 	if (power > 0.0f) return false;
@@ -707,9 +710,9 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
 	GSR_HIP_CHECK(hipMemsetAsync(gaussian_weights, 0, (size_t)P * sizeof(float), stream));
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
-	surfel_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+{ StageTimer st_(GSR_STAGE_PREPROCESS, stream); 	surfel_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
 	                                                              transMat_precomp, colors_precomp, refl_strengths, env_scope_mask, cam, radii, geom,
-	                                                              tiles_x, tiles_y, prefiltered);
+	                                                              tiles_x, tiles_y, prefiltered); }
 	GSR_LAUNCH_CHECK(debug, stream);
 
 	BinningState bin;
@@ -717,8 +720,8 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	if (R < 0) return R;
 
 	const int nblocks = ((ntiles + 7) / 8) * 8;
-	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
-	                                                      img.final_T, img.n_contrib, out_color, out_others, out_refl_strength_map, gaussian_weights);
+{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); 	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+	                                                      img.final_T, img.n_contrib, out_color, out_others, out_refl_strength_map, gaussian_weights); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
 }
@@ -751,15 +754,15 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
 	if (R > 0) {
 		const int nblocks = ((ntiles + 7) / 8) * 8;
-		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc);
+{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); 		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 	// scales == NULL selects the transMat_precomp path in the per-surfel backward (DSR backward.cu:639)
-	surfel_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, scales, rotations, geom.rec, cam,
+{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream); 	surfel_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, scales, rotations, geom.rec, cam,
 	                                                                  geom.acc, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths,
-	                                                                  dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot);
+	                                                                  dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return 0;
 }

@@ -157,6 +157,28 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
                                      const float* g_normal_world, float* g_normal_view, float* g_base,
                                      float* g_strength, float* g_cubemap, float* g_fail, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-stage device timing (bench.py's roofline leg).  When enabled, every stage launch is bracketed by
+ * hipEvents recorded on the stream the stage runs on; gsr_profile_collect() synchronises those events,
+ * adds up elapsed milliseconds and launch counts per stage since the last enable/collect, and resets.
+ * Stage ids: */
+#define GSR_STAGE_PREPROCESS 0
+#define GSR_STAGE_SCAN 1       /* inclusive scan + 4-byte num_rendered readback */
+#define GSR_STAGE_EMIT_KEYS 2
+#define GSR_STAGE_SORT 3
+#define GSR_STAGE_RANGES 4
+#define GSR_STAGE_RENDER_FWD 5
+#define GSR_STAGE_RENDER_BWD 6
+#define GSR_STAGE_PREPROCESS_BWD 7
+#define GSR_STAGE_REFL_FWD 8
+#define GSR_STAGE_REFL_BWD 9
+#define GSR_STAGE_CUBEMAP_FWD 10
+#define GSR_STAGE_CUBEMAP_BWD 11
+#define GSR_STAGE_COUNT 12
+int gsr_profile_enable(int on);
+int gsr_profile_collect(float* ms_out /* [GSR_STAGE_COUNT] */, int* launches_out /* [GSR_STAGE_COUNT] */);
+
 #ifdef __cplusplus
 }
 #endif

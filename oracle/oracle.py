@@ -83,7 +83,10 @@ class _Base:
         self._keep = None
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown
+            pass
 
     def free(self):
         if self.handle is not None:
