@@ -119,7 +119,8 @@ def main():
                                                        scales=scene.p["scales"], rotations=scene.p["rotations"],
                                                        env_scope_mask=scene.mask)
         final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], HWK, ct["R"], ct["T"])
-        info["R"] = base.grad_fn.num_rendered
+        if base.grad_fn is not None:
+            info["R"] = base.grad_fn.num_rendered
         return final, allmap
 
     def step():
