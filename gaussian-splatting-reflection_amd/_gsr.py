@@ -56,6 +56,8 @@ def _load():
     lib.gsr_deferred_reflection_forward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P]
     lib.gsr_deferred_reflection_backward.restype = c_int
     lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P]
+    lib.gsr_set_option.restype = c_int
+    lib.gsr_set_option.argtypes = [c_char_p, c_int]
     lib.gsr_profile_enable.restype = c_int
     lib.gsr_profile_enable.argtypes = [c_int]
     lib.gsr_profile_collect.restype = c_int
@@ -67,10 +69,14 @@ lib = _load()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_backward", "gsr_profile_enable", "gsr_profile_collect"]
+            "gsr_deferred_reflection_backward", "gsr_profile_enable", "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",
           "refl_bwd", "cubemap_fwd", "cubemap_bwd"]
+
+
+def set_option(name, value):
+    check(lib.gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")
 
 
 def profile_enable(on=True):

@@ -54,6 +54,9 @@ StageTimer::~StageTimer() {
 	g_prof_recs.push_back(r);
 }
 
+static int g_opt_cull = 1;
+int option_cull() { return g_opt_cull; }
+
 // getHigherMsb (DSR/DGR rasterizer_impl.cu:35-50)
 uint32_t higher_msb(uint32_t n) {
 	uint32_t msb = sizeof(n) * 4;
@@ -89,6 +92,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.point_offsets = c.take<uint32_t>(P);
 	g.clamped = c.take<uint8_t>(P);
 	g.rec = c.take<float4>(P * rec_f4);
+	g.bbox = c.take<float4>(P);
 	g.aux = c.take<float>(P * aux_floats);
 	g.acc = c.take<float>(P * acc_floats);
 	g.flags = c.take<int>(4);
@@ -247,6 +251,11 @@ extern "C" const char* gsr_last_error(void) { return g_err; }
 extern "C" int gsr_version(void) { return 100; }
 
 
+extern "C" int gsr_set_option(const char* name, int value) {
+	if (std::string(name) == "cull") { g_opt_cull = value ? 1 : 0; return 0; }
+	set_error("gsr_set_option: unknown option '%s'", name);
+	return GSR_E_INVALID;
+}
 extern "C" int gsr_profile_enable(int on) {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
 	for (ProfRec* r : g_prof_recs) g_prof_free.push_back(r);

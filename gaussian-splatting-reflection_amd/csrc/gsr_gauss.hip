@@ -158,6 +158,20 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	rec[1] = make_float4(conz, opacities[idx] * h_convolution_scaling, cr, cg);
 	rec[2] = make_float4(cb, normals[3 * idx], normals[3 * idx + 1], normals[3 * idx + 2]);
 	rec[3] = make_float4(refl[idx], 1.0f / pvz, 0.f, 0.f);
+	{
+		// Conservative bounds of the pixels this Gaussian can blend into: alpha = opac * exp(-q/2) >= 1/255 needs
+		// q = d^T conic d <= 2 ln(255 opac); the AABB of that ellipse is centre +- sqrt(q_max * cov_xx|yy)
+		// (cov after the +0.3 low-pass).  5 % + 0.1 margin on q_max, 1 % + 1 px on the box.
+		const float inf = __int_as_float(0x7f800000);
+		const float opac = opacities[idx] * h_convolution_scaling;
+		float4 bb = make_float4(inf, inf, -inf, -inf);
+		if (opac >= 1.0f / 255.0f) {
+			const float c2 = 2.0f * logf(255.0f * opac) * 1.05f + 0.1f;
+			const float hx = sqrtf(c2 * cx) * 1.01f + 1.0f, hy = sqrtf(c2 * cz) * 1.01f + 1.0f;
+			bb = make_float4(pix_x - hx, pix_y - hy, pix_x + hx, pix_y + hy);
+		}
+		g.bbox[idx] = bb;
+	}
 	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
 }
 
@@ -181,9 +195,9 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(256)
 gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                        const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
-                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_normal,
-                        float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
+                        const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
+                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                        float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
 	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
 	if (tile >= (uint32_t)ntiles) return;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -196,7 +210,10 @@ gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 	const int count = (int)(range.y - range.x);
 
 	__shared__ float4 s_rec[256 * G_REC_F4];
+	__shared__ float4 s_bbox[256];
 	__shared__ int s_done[4];
+	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
+	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
 	bool done = !inside;
 	float T = 1.0f;
@@ -219,35 +236,55 @@ gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
 			}
 		}
+		if (tid < nb) s_bbox[tid] = bbox[point_list[range.x + base + tid]];
 		__syncthreads();
 		if (!wave_done) {
-			for (int j = 0; j < nb; j++) {
-				const float4 r0 = s_rec[j * G_REC_F4 + 0];
-				const float4 r1 = s_rec[j * G_REC_F4 + 1];
-				float dx, dy, G, alpha;
-				bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
-				float test_T = 0.f;
-				if (ok) {
-					test_T = T * (1 - alpha);
-					if (test_T < 0.0001f) {
-						done = true;
-						ok = false;
-					}
+			// per-wave key compaction (see surfel_render_fwd_kernel)
+			unsigned long long hits[4];
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				const int e = h * 64 + lane;
+				bool hit = e < nb;
+				if (hit && cull) {
+					const float4 bb = s_bbox[e];
+					hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 				}
-				if (__ballot(ok) != 0ull) {
-					const float4 r2 = s_rec[j * G_REC_F4 + 2];
-					const float4 r3 = s_rec[j * G_REC_F4 + 3];
+				hits[h] = __ballot(hit);
+			}
+			bool all_done = false;
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				unsigned long long mm = hits[h];
+				while (mm != 0ull && !all_done) {
+					const int j = h * 64 + (int)__builtin_ctzll(mm);
+					mm &= mm - 1ull;
+					const float4 r0 = s_rec[j * G_REC_F4 + 0];
+					const float4 r1 = s_rec[j * G_REC_F4 + 1];
+					float dx, dy, G, alpha;
+					bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+					float test_T = 0.f;
 					if (ok) {
-						const float w = alpha * T;
-						C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
-						N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
-						RS = fmaf(r3.x, w, RS);
-						if (INVDEPTH) ID = fmaf(r3.y, w, ID);
-						T = test_T;
-						last_contributor = (uint32_t)(base + j + 1);
+						test_T = T * (1 - alpha);
+						if (test_T < 0.0001f) {
+							done = true;
+							ok = false;
+						}
 					}
-				} else if (__ballot(!done) == 0ull) {
-					break;
+					if (__ballot(ok) != 0ull) {
+						const float4 r2 = s_rec[j * G_REC_F4 + 2];
+						const float4 r3 = s_rec[j * G_REC_F4 + 3];
+						if (ok) {
+							const float w = alpha * T;
+							C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
+							N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
+							RS = fmaf(r3.x, w, RS);
+							if (INVDEPTH) ID = fmaf(r3.y, w, ID);
+							T = test_T;
+							last_contributor = (uint32_t)(base + j + 1);
+						}
+					} else if (__ballot(!done) == 0ull) {
+						all_done = true;
+					}
 				}
 			}
 		}
@@ -276,9 +313,10 @@ gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(256)
 gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                        const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_Ts,
-                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dnormal_map,
-                        const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_invdepths, float* __restrict__ acc) {
+                        const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
+                        const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                        const float* __restrict__ dL_dnormal_map, const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_invdepths,
+                        float* __restrict__ acc) {
 	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
 	if (tile >= (uint32_t)ntiles) return;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -293,7 +331,10 @@ gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 	const size_t pix = (size_t)W * py + px;
 
 	__shared__ float4 s_rec[G_BWD_BATCH * G_REC_F4];
+	__shared__ float4 s_bbox[G_BWD_BATCH];
 	__shared__ uint32_t s_id[G_BWD_BATCH];
+	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
+	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 	__shared__ float4 s_slab[4][G_BWD_BATCH][G_ACC_F / 4];
 	__shared__ unsigned long long s_touched[4];
 
@@ -320,12 +361,26 @@ gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 			if (i < nb) {
 				const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
 				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
-				if ((tid & 3) == 0) s_id[i] = id;
+				if ((tid & 3) == 0) {
+					s_id[i] = id;
+					s_bbox[i] = bbox[id];
+				}
 			}
 		}
 		__syncthreads();
 		unsigned long long touched = 0ull;
-		for (int j = 0; j < nb; j++) {
+		unsigned long long mm;
+		{
+			bool hit = lane < nb;
+			if (hit && cull) {
+				const float4 bb = s_bbox[lane];
+				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+			}
+			mm = __ballot(hit);
+		}
+		while (mm != 0ull) {
+			const int j = (int)__builtin_ctzll(mm);
+			mm &= mm - 1ull;
 			const int contributor = count - 1 - (base + j);  // index in the front-to-back list
 			const float4 r0 = s_rec[j * G_REC_F4 + 0];
 			const float4 r1 = s_rec[j * G_REC_F4 + 1];
@@ -656,11 +711,13 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 
 	const int nblocks = ((ntiles + 7) / 8) * 8;
 	if (out_invdepth)
-		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+		                                                          option_cull(), background,
 		                                                          img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
 		                                                          out_invdepth); }
 	else
-		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+		                                                          option_cull(), background,
 		                                                           img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
 		                                                           nullptr); }
 	GSR_LAUNCH_CHECK(debug, stream);
@@ -698,10 +755,12 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 		if (dL_invdepths)
 			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                          geom.bbox, option_cull(),
 			                                                          img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
 			                                                          dL_invdepths, geom.acc); }
 		else
 			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                          geom.bbox, option_cull(),
 			                                                           img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
 			                                                           nullptr, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);

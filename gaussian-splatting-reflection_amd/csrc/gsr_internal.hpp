@@ -67,6 +67,8 @@ struct GeomState {
 	uint32_t* point_offsets; // P        inclusive scan
 	uint8_t* clamped;        // P        bit c set = SH colour channel c clamped at 0
 	float4* rec;             // P*REC_F4
+	float4* bbox;            // P        conservative screen-space bounds (xmin,ymin,xmax,ymax) of the pixels a
+	                         //          Gaussian can blend into; used for per-wave culling in the tile kernels
 	float* aux;              // G: cov3D P*6.  S: unused
 	float* acc;              // backward accumulator P*ACC_F (zeroed by backward)
 	int* flags;              // 4 ints: [0] prefiltered-trap flag
@@ -91,6 +93,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int planes_n, size_t* total);
 BinningState carve_binning(void* buf, size_t R, size_t sort_temp_bytes, size_t* total);
 
+int option_cull();   // 1 (default): per-wave bounding-box culling in the tile kernels; 0: evaluate every list entry
 size_t scan_temp_bytes(size_t P);
 size_t sort_temp_bytes(size_t R, int end_bit);
 uint32_t higher_msb(uint32_t n);

@@ -93,6 +93,41 @@ __device__ __forceinline__ void compute_transmat(float px, float py, float pz, c
 	normal = f3(vm[0] * nx + vm[4] * ny + vm[8] * nz, vm[1] * nx + vm[5] * ny + vm[9] * nz, vm[2] * nx + vm[6] * ny + vm[10] * nz);
 }
 
+// Conservative screen-space bounds of the pixels a surfel can blend into (alpha >= 1/255), for the per-wave
+// culling of the tile kernels.  alpha = min(0.99, opa * exp(-rho/2)) >= 1/255 needs rho <= rho_max =
+// 2 ln(255 opa), with rho = min(rho3d, rho2d):
+//   * rho3d <= c2: inside the projected ellipse u^2+v^2 <= c2 of the splat; its exact screen AABB is the
+//     compute_aabb formula of the reference (DSR forward.cu:119-145) evaluated at cutoff^2 = c2;
+//   * rho2d <= c2: inside the disc of radius sqrt(c2/2) about the low-pass centre (the cutoff-3 AABB centre).
+// c2 carries a 5 % + 0.1 margin over rho_max and the box 2 % + >= 1 px (the per-pixel evaluation of rho3d
+// cancels catastrophically, ~1e-4 relative).  If the cutoff circle reaches the camera plane (d >= 0) the
+// projection is unbounded and the box is infinite; opa < 1/255 can never blend and the box is empty.
+// Culling with these bounds leaves every output bit-identical (tests/test_gpu_parity.py::test_cull_*).
+__device__ __forceinline__ float4 surfel_bbox(const M3& T, float cx, float cy, float opa) {
+	const float inf = __int_as_float(0x7f800000);
+	if (!(opa >= 1.0f / 255.0f)) return make_float4(inf, inf, -inf, -inf);
+	const float rho_max = 2.0f * logf(255.0f * opa);
+	const float c2 = rho_max * 1.05f + 0.1f;
+	float x0 = -inf, y0 = -inf, x1 = inf, y1 = inf;
+	const float tw2 = T.m[2][2] * T.m[2][2];
+	const float d = c2 * (T.m[2][0] * T.m[2][0] + T.m[2][1] * T.m[2][1]) - tw2;
+	if (d < -1e-5f * tw2) {
+		const float fa = c2 / d, fb = -1.0f / d;
+		const float px = fa * (T.m[0][0] * T.m[2][0] + T.m[0][1] * T.m[2][1]) + fb * (T.m[0][2] * T.m[2][2]);
+		const float py = fa * (T.m[1][0] * T.m[2][0] + T.m[1][1] * T.m[2][1]) + fb * (T.m[1][2] * T.m[2][2]);
+		const float hx2 = px * px - (fa * (T.m[0][0] * T.m[0][0] + T.m[0][1] * T.m[0][1]) + fb * (T.m[0][2] * T.m[0][2]));
+		const float hy2 = py * py - (fa * (T.m[1][0] * T.m[1][0] + T.m[1][1] * T.m[1][1]) + fb * (T.m[1][2] * T.m[1][2]));
+		const float hx = sqrtf(fmaxf(hx2, 0.f)) * 1.02f + 1.0f + 1e-3f * fabsf(px);
+		const float hy = sqrtf(fmaxf(hy2, 0.f)) * 1.02f + 1.0f + 1e-3f * fabsf(py);
+		x0 = px - hx; x1 = px + hx; y0 = py - hy; y1 = py + hy;
+	}
+	const float r = sqrtf(0.5f * c2) + 1.0f;
+	x0 = fminf(x0, cx - r); x1 = fmaxf(x1, cx + r);
+	y0 = fminf(y0, cy - r); y1 = fmaxf(y1, cy + r);
+	// NaN anywhere -> comparisons in the kernels evaluate to "hit" (conservative)
+	return make_float4(x0, y0, x1, y1);
+}
+
 // preprocessCUDA forward (DSR forward.cu:149-253); FMA contraction off (integer outputs bit-exact vs oracle).
 __global__ void __launch_bounds__(256)
 surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
@@ -165,6 +200,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
 	const float maskv = (env_scope_mask != nullptr && env_scope_mask[idx]) ? 1.0f : 0.0f;
+	g.bbox[idx] = surfel_bbox(T, pxi, pyi, opacities[idx]);
 	float4* rec = g.rec + (size_t)idx * S_REC_F4;
 	rec[0] = make_float4(pxi, pyi, T.m[0][0], T.m[0][1]);
 	rec[1] = make_float4(T.m[0][2], T.m[1][0], T.m[1][1], T.m[1][2]);
@@ -194,7 +230,7 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	o.pz = o.kx * o.ly - o.ky * o.lx;
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
 	if (!unstable) {
-		const float inv_pz = 1.0f / o.pz;
+		const float inv_pz = __builtin_amdgcn_rcpf(o.pz);  // v_rcp_f32 (1 ulp); shared by forward and backward
 		o.sx = ppx * inv_pz;
 		o.sy = ppy * inv_pz;
 	} else {
@@ -218,9 +254,9 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 // renderCUDA forward (DSR forward.cu:258-489)
 __global__ void __launch_bounds__(256)
 surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                         const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
-                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_others,
-                         float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
+                         const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
+                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                         float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
 	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
 	if (tile >= (uint32_t)ntiles) return;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -234,9 +270,13 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 
 	constexpr int BATCH = 128;
 	__shared__ float4 s_rec[BATCH * S_REC_F4];   // 10 KB
+	__shared__ float4 s_bbox[BATCH];
 	__shared__ uint32_t s_id[BATCH];
 	__shared__ float s_wmax[4][BATCH];           // per-wave max blend weight of this batch
 	__shared__ int s_done[4];
+	// pixel bounds of this wave's 8x8 quadrant (for the per-wave culling)
+	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
+	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
 	bool done = !inside;
 	float T = 1.0f;
@@ -255,53 +295,80 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
 			const uint32_t id = point_list[range.x + base + i];
 			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
-			if (q == 0) s_id[i] = id;
 		}
-		if (tid < BATCH) { s_wmax[0][tid] = 0.f; s_wmax[1][tid] = 0.f; s_wmax[2][tid] = 0.f; s_wmax[3][tid] = 0.f; }
+		if (tid < BATCH) {
+			if (tid < nb) {
+				const uint32_t id = point_list[range.x + base + tid];
+				s_id[tid] = id;
+				s_bbox[tid] = bbox[id];
+			}
+			s_wmax[0][tid] = 0.f; s_wmax[1][tid] = 0.f; s_wmax[2][tid] = 0.f; s_wmax[3][tid] = 0.f;
+		}
 		__syncthreads();
 		if (!wave_done) {
-			for (int j = 0; j < nb; j++) {
-				const float4 r0 = s_rec[j * S_REC_F4 + 0];
-				const float4 r1 = s_rec[j * S_REC_F4 + 1];
-				const float4 r2 = s_rec[j * S_REC_F4 + 2];
-				const float4 r3 = s_rec[j * S_REC_F4 + 3];
-				SurfelPair o;
-				bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
-				float test_T = 0.f;
-				if (ok) {
-					test_T = T * (1 - o.alpha);
-					if (test_T < 0.0001f) {
-						done = true;
-						ok = false;
-					}
+			// Per-wave key compaction: one ballot per 64 entries marks the Gaussians whose conservative bounds
+			// reach this wave's 8x8 pixels; the wave then walks only the set bits (scalar s_ff1), so culled
+			// entries cost nothing in the blend loop.
+			unsigned long long hits[BATCH / 64];
+#pragma unroll
+			for (int h = 0; h < BATCH / 64; h++) {
+				const int e = h * 64 + lane;
+				bool hit = e < nb;
+				if (hit && cull) {
+					const float4 bb = s_bbox[e];
+					hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 				}
-				if (__ballot(ok) != 0ull) {
-					const float4 r4 = s_rec[j * S_REC_F4 + 4];
-					float w = 0.f;
+				hits[h] = __ballot(hit);
+			}
+			bool all_done = false;
+#pragma unroll
+			for (int h = 0; h < BATCH / 64; h++) {
+				unsigned long long mm = hits[h];
+				while (mm != 0ull && !all_done) {
+					const int j = h * 64 + (int)__builtin_ctzll(mm);
+					mm &= mm - 1ull;
+					const float4 r0 = s_rec[j * S_REC_F4 + 0];
+					const float4 r1 = s_rec[j * S_REC_F4 + 1];
+					const float4 r2 = s_rec[j * S_REC_F4 + 2];
+					const float4 r3 = s_rec[j * S_REC_F4 + 3];
+					SurfelPair o;
+					bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
+					float test_T = 0.f;
 					if (ok) {
-						w = o.alpha * T;
-						const float A = 1 - T;
-						const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR / o.depth);
-						distortion += (m * m * A + M2 - 2 * m * M1) * w;
-						Dp += o.depth * w;
-						M1 += m * w;
-						M2 += m * m * w;
-						if (T > 0.5f) {
-							median_depth = o.depth;
-							median_contributor = (float)(base + j + 1);
+						test_T = T * (1 - o.alpha);
+						if (test_T < 0.0001f) {
+							done = true;
+							ok = false;
 						}
-						N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
-						C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
-						RS = fmaf(r4.z, w, RS);
-						if (r4.w != 0.f) mask = 1.0f;
-						T = test_T;
-						last_contributor = (uint32_t)(base + j + 1);
 					}
-					// gaussian_weights (forward.cu:458-459): max over the wave's pixels, merged per tile below
-					const float wm = wave_max_pos(w);
-					if (lane == 63) s_wmax[wave][j] = wm;
-				} else if (__ballot(!done) == 0ull) {
-					break;
+					if (__ballot(ok) != 0ull) {
+						const float4 r4 = s_rec[j * S_REC_F4 + 4];
+						float w = 0.f;
+						if (ok) {
+							w = o.alpha * T;
+							const float A = 1 - T;
+							const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(o.depth));
+							distortion += (m * m * A + M2 - 2 * m * M1) * w;
+							Dp += o.depth * w;
+							M1 += m * w;
+							M2 += m * m * w;
+							if (T > 0.5f) {
+								median_depth = o.depth;
+								median_contributor = (float)(base + j + 1);
+							}
+							N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
+							C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
+							RS = fmaf(r4.z, w, RS);
+							if (r4.w != 0.f) mask = 1.0f;
+							T = test_T;
+							last_contributor = (uint32_t)(base + j + 1);
+						}
+						// gaussian_weights (forward.cu:458-459): max over the wave's pixels, merged per tile below
+						const float wm = wave_max_pos(w);
+						if (lane == 63) s_wmax[wave][j] = wm;
+					} else if (__ballot(!done) == 0ull) {
+						all_done = true;
+					}
 				}
 			}
 		}
@@ -341,9 +408,9 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 #define S_BWD_BATCH 64
 __global__ void __launch_bounds__(256)
 surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                         const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_Ts,
-                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
-                         const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
+                         const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
+                         const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                         const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
 	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
 	if (tile >= (uint32_t)ntiles) return;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -358,9 +425,12 @@ surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 	const size_t pix = (size_t)W * py + px;
 
 	__shared__ float4 s_rec[S_BWD_BATCH * S_REC_F4];
+	__shared__ float4 s_bbox[S_BWD_BATCH];
 	__shared__ uint32_t s_id[S_BWD_BATCH];
 	__shared__ float4 s_slab[4][S_BWD_BATCH][S_ACC_F / 4];
 	__shared__ unsigned long long s_touched[4];
+	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
+	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
@@ -392,11 +462,28 @@ surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
 			const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
 			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
-			if (q == 0) s_id[i] = id;
+		}
+		if (tid < nb) {
+			const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + tid)];
+			s_id[tid] = id;
+			s_bbox[tid] = bbox[id];
 		}
 		__syncthreads();
 		unsigned long long touched = 0ull;
-		for (int j = 0; j < nb; j++) {
+		// per-wave culling: ballot of "bounds reach my 8x8 pixels AND someone in the wave still has this entry
+		// before its last contributor"; walk the set bits only
+		unsigned long long mm;
+		{
+			bool hit = lane < nb;
+			if (hit && cull) {
+				const float4 bb = s_bbox[lane];
+				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+			}
+			mm = __ballot(hit);
+		}
+		while (mm != 0ull) {
+			const int j = (int)__builtin_ctzll(mm);
+			mm &= mm - 1ull;
 			const int contributor = count - 1 - (base + j);
 			const float4 r0 = s_rec[j * S_REC_F4 + 0];
 			const float4 r1 = s_rec[j * S_REC_F4 + 1];
@@ -425,7 +512,7 @@ surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 				dL_dalpha += (r4.z - acc_r) * dr;
 				v[SA_REFL] = dchannel_dcolor * dr;
 				float dL_dz = 0.0f, dL_dweight = 0.f;
-				const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR / c_d);
+				const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(c_d));
 				const float dmd_dd = (S_FAR * S_NEAR) / ((S_FAR - S_NEAR) * c_d * c_d);
 				if (contributor == median_contributor - 1) dL_dz += dL_dmedian_depth;
 				dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
@@ -720,7 +807,8 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	if (R < 0) return R;
 
 	const int nblocks = ((ntiles + 7) / 8) * 8;
-{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); 	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, background,
+{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); 	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+	                                                      option_cull(), background,
 	                                                      img.final_T, img.n_contrib, out_color, out_others, out_refl_strength_map, gaussian_weights); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
@@ -755,6 +843,7 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 	if (R > 0) {
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream); 		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+		                                                      geom.bbox, option_cull(),
 		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}

@@ -176,6 +176,9 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
 #define GSR_STAGE_CUBEMAP_FWD 10
 #define GSR_STAGE_CUBEMAP_BWD 11
 #define GSR_STAGE_COUNT 12
+/* Test/diagnostic switches.  "cull" (default 1): per-wave conservative bounding-box culling inside the tile
+ * kernels; outputs are bit-identical with 0 and 1 (it only skips pairs that cannot blend). */
+int gsr_set_option(const char* name, int value);
 int gsr_profile_enable(int on);
 int gsr_profile_collect(float* ms_out /* [GSR_STAGE_COUNT] */, int* launches_out /* [GSR_STAGE_COUNT] */);
 

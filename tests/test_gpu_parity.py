@@ -120,3 +120,41 @@ def test_c2_surfel_fwd_bwd():
 
 def test_c2_gauss_fwd_bwd():
     _run_gauss(100_000, 800, 800, 1002, -3.6, 3, (0, 0, 0), antialiasing=True)
+
+
+# ---- per-wave culling must not change a single bit of any output (it only skips pairs that cannot blend) ----
+@pytest.mark.parametrize("variant", ["S", "G"])
+def test_cull_is_bit_exact(variant):
+    import _gsr
+    P, W, H = 30_000, 400, 300
+    kw, cam, sc = scene_kwargs(variant, P, W, H, 21, -3.3, 3, (0.3, 0.2, 0.1))
+    # a few huge / degenerate / near-plane Gaussians to exercise the unbounded-box paths
+    kw["scales"][:50] *= 40.0
+    kw["means3D"][50:100, 2] = 0.25
+    kw["opacities"][100:150] = 0.003
+    g = S.make_upstream_grads(H, W, 21)
+    res = []
+    for cull in (0, 1):
+        _gsr.set_option("cull", cull)
+        try:
+            if variant == "S":
+                hip = HipSurfel(kw)
+                out = hip.out()
+                gh = hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+            else:
+                hip = HipGauss(kw, antialiasing=True)
+                out = hip.out()
+                gh = hip.backward(g["dL_dcolor"], g["dL_dinvdepth"], g["dL_dnormal"], g["dL_drefl"])
+            res.append((out, gh, hip.state("n_contrib"), hip.state("final_T")))
+        finally:
+            _gsr.set_option("cull", 1)
+    (o0, g0, n0, t0), (o1, g1, n1, t1) = res
+    for k in o0:
+        if isinstance(o0[k], np.ndarray):
+            np.testing.assert_array_equal(o0[k], o1[k], err_msg=k)
+    np.testing.assert_array_equal(n0, n1)
+    np.testing.assert_array_equal(t0, t1)
+    # gradients are float-atomic sums (order-dependent in the last bits): compare tightly, not bitwise
+    for k in g0:
+        if g0[k] is not None:
+            assert rel_maxnorm(g1[k], g0[k]) <= 1e-5, k
