@@ -55,7 +55,7 @@ def _load():
     lib.gsr_deferred_reflection_forward.restype = c_int
     lib.gsr_deferred_reflection_forward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P]
     lib.gsr_deferred_reflection_backward.restype = c_int
-    lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P]
+    lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P, P]
     lib.gsr_set_option.restype = c_int
     lib.gsr_set_option.argtypes = [c_char_p, c_int]
     lib.gsr_profile_enable.restype = c_int

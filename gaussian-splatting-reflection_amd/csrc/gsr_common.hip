@@ -56,6 +56,8 @@ StageTimer::~StageTimer() {
 
 static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
+static int g_opt_dev = 0;
+int option_dev() { return g_opt_dev; }
 
 // getHigherMsb (DSR/DGR rasterizer_impl.cu:35-50)
 uint32_t higher_msb(uint32_t n) {
@@ -253,6 +255,7 @@ extern "C" int gsr_version(void) { return 100; }
 
 extern "C" int gsr_set_option(const char* name, int value) {
 	if (std::string(name) == "cull") { g_opt_cull = value ? 1 : 0; return 0; }
+	if (std::string(name) == "dev") { g_opt_dev = value; return 0; }
 	set_error("gsr_set_option: unknown option '%s'", name);
 	return GSR_E_INVALID;
 }

@@ -359,65 +359,99 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 	out_nworld[2 * HW + pix] = o.nz;
 }
 
+// Backward of the fused pass.  Four lanes per pixel: lane c < 3 owns colour channel c (lane 3 only helps with
+// the shared index math).  The texel gradients go to a channel-INTERLEAVED scratch [6][L][L][4] so that the
+// three channel atomics of one texel (and usually its x-neighbour) fall into one 64-byte line: float atomics
+// execute at the memory side per 64-byte request, so this issues ~4x fewer requests than per-channel planes
+// (measured 2.2 ms -> see DESIGN.md).  `unpack_cubemap_grad_kernel` then adds the scratch into [6,3,L,L].
+__device__ __forceinline__ float quad_sum(float v) {
+	v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+	v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+	return v;
+}
 __global__ void __launch_bounds__(256)
 deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
                          const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
                          int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color, const float* __restrict__ g_nworld,
                          float* __restrict__ g_normal_view, float* __restrict__ g_base, float* __restrict__ g_strength,
-                         float* __restrict__ g_cubemap, float* __restrict__ g_fail) {
+                         float* __restrict__ g_scratch, float* __restrict__ g_fail) {
 	const size_t HW = (size_t)W * H;
-	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (pix >= HW) return;
-	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
+	const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t pix = gid >> 2;
+	const int ch = (int)(gid & 3);
+	const bool live = pix < HW;           // whole quads are live or dead together
+	const size_t p = live ? pix : 0;
+	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
 	ReflPixel o;
-	refl_pixel(cam, normal_view[pix], normal_view[HW + pix], normal_view[2 * HW + pix], px, py, o);
+	refl_pixel(cam, normal_view[p], normal_view[HW + p], normal_view[2 * HW + p], px, py, o);
 	const bool fail = (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f);
+	const bool chan = live && ch < 3;
+	const int c = ch < 3 ? ch : 0;
 	Seamless s;
 	int face = 0;
-	float c[3];
+	float cval;
+	size_t i00 = 0, i01 = 0, i10 = 0, i11 = 0;
+	float v00 = 0, v01 = 0, v10 = 0, v11 = 0;
 	if (fail) {
-		c[0] = fail_value[0]; c[1] = fail_value[1]; c[2] = fail_value[2];
+		cval = fail_value[c];
+		s.kx = 0; s.ky = 0; s.flag = 0; s.is_vertex = false;
 	} else {
 		float u, v;
 		cube_uv(o.rx, o.ry, o.rz, u, v, face);
 		seamless_index(face, L, u, v, s);
-#pragma unroll
-		for (int ch = 0; ch < 3; ch++) {
-			const float v00 = cubemap[texel(s.f[0], ch, s.y[0], s.x[0], 3, L)];
-			const float v01 = cubemap[texel(s.f[1], ch, s.y[1], s.x[1], 3, L)];
-			const float v10 = cubemap[texel(s.f[2], ch, s.y[2], s.x[2], 3, L)];
-			const float v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], ch, s.y[3], s.x[3], 3, L)];
-			c[ch] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
-		}
+		i00 = texel(s.f[0], c, s.y[0], s.x[0], 3, L); i01 = texel(s.f[1], c, s.y[1], s.x[1], 3, L);
+		i10 = texel(s.f[2], c, s.y[2], s.x[2], 3, L);
+		v00 = cubemap[i00]; v01 = cubemap[i01]; v10 = cubemap[i10];
+		if (s.is_vertex) v11 = (v00 + v01 + v10) / 3.f;
+		else { i11 = texel(s.f[3], c, s.y[3], s.x[3], 3, L); v11 = cubemap[i11]; }
+		cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
 	}
-	const float sv = strength[pix];
+	const float sv = strength[p];
+	const float rc = sigmoidf_(cval);
 	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
-#pragma unroll
-	for (int ch = 0; ch < 3; ch++) {
-		const float rc = sigmoidf_(c[ch]);
-		const float gf = g_final[ch * HW + pix];
-		const float b = base[ch * HW + pix];
-		g_base[ch * HW + pix] = (1 - sv) * gf;
-		gs += gf * (rc - b);
+	if (chan) {
+		const float gf = g_final[c * HW + p];
+		const float b = base[c * HW + p];
+		g_base[c * HW + p] = (1 - sv) * gf;
+		gs = gf * (rc - b);
 		float gc = sv * gf;
-		if (g_refl_color) gc += g_refl_color[ch * HW + pix];
+		if (g_refl_color) gc += g_refl_color[c * HW + p];
 		const float graw = gc * rc * (1 - rc);   // sigmoid'
 		if (fail) {
-			atomicAdd(g_fail + ch, graw);
+			atomicAdd(g_fail + c, graw);
 		} else {
-			float gu, gv, a, bb, cc;
-			seamless_bwd_channel(s, ch, 3, L, cubemap, g_cubemap, graw, gu, gv);
-			cube_uv_backward(face, o.rx, o.ry, o.rz, gu, gv, a, bb, cc);
-			grx += a; gry += bb; grz += cc;
+			// interleaved scratch index of texel (f, y, x), channel c
+			auto sidx = [&](int k) -> size_t { return ((((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) << 2) + c; };
+			if (s.is_vertex) {
+				const float extra_g = s.ky * s.kx / 3.f;
+				atomicAdd(g_scratch + sidx(0), ((1 - s.ky) * (1 - s.kx) + extra_g) * graw);
+				atomicAdd(g_scratch + sidx(1), ((1 - s.ky) * s.kx + extra_g) * graw);
+				atomicAdd(g_scratch + sidx(2), ((s.ky * (1 - s.kx)) + extra_g) * graw);
+			} else {
+				atomicAdd(g_scratch + sidx(0), (1 - s.ky) * (1 - s.kx) * graw);
+				atomicAdd(g_scratch + sidx(1), (1 - s.ky) * s.kx * graw);
+				atomicAdd(g_scratch + sidx(2), s.ky * (1 - s.kx) * graw);
+				atomicAdd(g_scratch + sidx(3), s.ky * s.kx * graw);
+			}
+			float lg0 = (1 - s.ky) * (v01 - v00) + s.ky * (v11 - v10);
+			float lg1 = (1 - s.kx) * (v10 - v00) + s.kx * (v11 - v01);
+			lg0 *= 0.5f * (float)L * graw;
+			lg1 *= 0.5f * (float)L * graw;
+			if (s.flag & 1) lg0 = -lg0;
+			if (s.flag & 4) lg1 = -lg1;
+			lg1 = -lg1;
+			cube_uv_backward(face, o.rx, o.ry, o.rz, lg0, lg1, grx, gry, grz);
 		}
 	}
-	g_strength[pix] = gs;
+	// sum the per-channel pieces over the quad (lane 3 contributes zeros)
+	gs = quad_sum(gs); grx = quad_sum(grx); gry = quad_sum(gry); grz = quad_sum(grz);
+	if (live && ch == 3) g_strength[p] = gs;
 	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
 	const float grn = grx * o.nx + gry * o.ny + grz * o.nz;
 	float gnx = -2.f * (o.dn * grx + grn * o.dx);
 	float gny = -2.f * (o.dn * gry + grn * o.dy);
 	float gnz = -2.f * (o.dn * grz + grn * o.dz);
-	if (g_nworld) { gnx += g_nworld[pix]; gny += g_nworld[HW + pix]; gnz += g_nworld[2 * HW + pix]; }
+	if (g_nworld) { gnx += g_nworld[p]; gny += g_nworld[HW + p]; gnz += g_nworld[2 * HW + p]; }
 	// n = nw / (|nw| + eps): g_nw = g_n / (len+eps) - nw (nw.g_n) / (len (len+eps)^2)   (0 subgradient at len = 0)
 	const float inv = 1.0f / (o.len + 1e-6f);
 	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
@@ -425,9 +459,20 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv / o.len;
 		gwx -= o.nwx * k; gwy -= o.nwy * k; gwz -= o.nwz * k;
 	}
-	g_normal_view[pix] = gwx * cam[0] + gwy * cam[3] + gwz * cam[6];
-	g_normal_view[HW + pix] = gwx * cam[1] + gwy * cam[4] + gwz * cam[7];
-	g_normal_view[2 * HW + pix] = gwx * cam[2] + gwy * cam[5] + gwz * cam[8];
+	if (chan) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
+}
+
+// scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] +=
+__global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap, int L) {
+	const size_t n = (size_t)6 * L * L;
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= n) return;
+	const size_t LL = (size_t)L * L;
+	const size_t f = t / LL, r = t - f * LL;
+	const float4 g = scratch[t];
+	g_cubemap[(f * 3 + 0) * LL + r] += g.x;
+	g_cubemap[(f * 3 + 1) * LL + r] += g.y;
+	g_cubemap[(f * 3 + 2) * LL + r] += g.z;
 }
 
 }  // namespace gsr
@@ -479,17 +524,21 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
                                                 const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                 const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                 float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
-                                                void* stream_) {
+                                                float* scratch, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
-	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || L == 0) {
+	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
 		set_error("gsr_deferred_reflection_backward: invalid argument");
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
-{ StageTimer st_(GSR_STAGE_REFL_BWD, stream); 	deferred_refl_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
-	                                                                         (int)L, width, height, g_final, g_refl_color, g_normal_world,
-	                                                                         g_normal_view, g_base, g_strength, g_cubemap, g_fail); }
+	const size_t ntex = (size_t)6 * L * L;
+	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, ntex * 4 * sizeof(float), stream));
+	{ StageTimer st_(GSR_STAGE_REFL_BWD, stream);
+	deferred_refl_bwd_kernel<<<(unsigned)((HW * 4 + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+	                                                                             (int)L, width, height, g_final, g_refl_color, g_normal_world,
+	                                                                             g_normal_view, g_base, g_strength, scratch, g_fail);
+	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, (int)L); }
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }

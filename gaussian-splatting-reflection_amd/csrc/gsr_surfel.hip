@@ -230,7 +230,7 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	o.pz = o.kx * o.ly - o.ky * o.lx;
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
 	if (!unstable) {
-		const float inv_pz = __builtin_amdgcn_rcpf(o.pz);  // v_rcp_f32 (1 ulp); shared by forward and backward
+		const float inv_pz = 1.0f / o.pz;  // IEEE division: the backward is ill-conditioned enough that a 1-ulp rcp costs 1e-4 in dL_dscale
 		o.sx = ppx * inv_pz;
 		o.sy = ppy * inv_pz;
 	} else {
@@ -409,7 +409,7 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 __global__ void __launch_bounds__(256)
 surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                          const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
-                         const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                         int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                          const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
 	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
 	if (tile >= (uint32_t)ntiles) return;
@@ -559,9 +559,11 @@ surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 				}
 				v[SA_OPAC] = G * dL_dalpha;
 			}
-			wave_sum8(v);
-			wave_sum8(v + 8);
-			wave_sum4(v + 16);
+			if (!(dev_flags & 2)) {
+				wave_sum8(v);
+				wave_sum8(v + 8);
+				wave_sum4(v + 16);
+			}
 			if (lane == 63) {
 				s_slab[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
 				s_slab[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -585,7 +587,7 @@ surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 					any = true;
 				}
 			}
-			if (any) {
+			if (any && !(dev_flags & 1)) {
 				float* dst = acc + (size_t)s_id[i] * S_ACC_F + q * 4;
 				atomicAdd(dst + 0, s.x);
 				atomicAdd(dst + 1, s.y);
@@ -843,7 +845,7 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 	if (R > 0) {
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream); 		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-		                                                      geom.bbox, option_cull(),
+		                                                      geom.bbox, option_cull(), option_dev(),
 		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}

@@ -1,0 +1,171 @@
+"""GPU parity: cubemap encoder (all three interpolation modes) and the fused deferred-reflection pass vs the
+CPU oracle (oracle/oracle_cubemap.cpp) and vs the reference's own op-by-op composition
+(gaussian_renderer/__init__.py:22-35,148,178-179,197-199) evaluated on the CPU in float64."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import S, rel_maxnorm
+
+pytestmark = pytest.mark.gpu
+
+
+def _dirs(B, seed, L):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(B, 3, generator=g)
+    # add exact face centres, edges, corners and the zero vector (fail value path)
+    special = torch.tensor([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [1, -1, 0], [-1, 1, 0.0],
+                            [1, 1, 1], [-1, 1, 1], [1, -1, -1], [-1, -1, -1], [0, 0, 0], [1, 0.999, 0.2], [0.3, 1, 0.9995], [1, 1 - 1.0 / L, 1 - 1.0 / L]],
+                           dtype=torch.float32)
+    # directions hugging cube edges / corners so that the seamless branches are hit often
+    near = torch.sign(torch.randn(B // 4, 3, generator=g)) * (1 - 0.02 * torch.rand(B // 4, 3, generator=g))
+    return torch.cat([d, special, near], 0).contiguous()
+
+
+@pytest.mark.parametrize("interp,seamless", [(0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("L,C", [(16, 3), (8, 5)])
+def test_cubemap_forward_backward_vs_oracle(interp, seamless, L, C):
+    from oracle import oracle as orc
+    from cubemapencoder.cubemap_encoder import _backend
+    d = _dirs(20000, 3, L)
+    B = d.shape[0]
+    g = torch.Generator().manual_seed(5)
+    cm = (torch.rand(6, C, L, L, generator=g) - 0.5)
+    fv = torch.randn(C, generator=g)
+    go = torch.randn(C, B, generator=g)
+    out = torch.empty(C, B, device="cuda")
+    _backend.cubemap_encode_forward(d.cuda(), cm.cuda(), fv.cuda(), out, interp, seamless, B, C, L)
+    ref = orc.cubemap_forward(d.numpy(), cm.numpy(), fv.numpy(), interp, seamless)
+    # -use_fast_math in the reference build: tolerance covers approximate division
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    gcm = torch.zeros_like(cm, device="cuda")
+    gin = torch.empty(B, 3, device="cuda")
+    gf = torch.zeros(C, device="cuda")
+    _backend.cubemap_encode_backward(go.cuda(), d.cuda(), cm.cuda(), gcm, gin, gf, interp, seamless, B, C, L)
+    rin, rcm, rf = orc.cubemap_backward(go.numpy(), d.numpy(), cm.numpy(), interp, seamless)
+    assert rel_maxnorm(gcm.cpu().numpy(), rcm) <= 1e-5
+    assert rel_maxnorm(gf.cpu().numpy(), rf) <= 1e-5
+    assert rel_maxnorm(gin.cpu().numpy(), rin) <= 1e-4
+
+
+def test_cubemap_encoder_module_autograd():
+    from oracle import oracle as orc
+    from cubemapencoder import CubemapEncoder
+    enc = CubemapEncoder(output_dim=3, resolution=32).cuda()
+    d = _dirs(5000, 9, 32).cuda().requires_grad_(True)
+    y = enc(d)
+    assert y.shape == (d.shape[0], 3)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    tex = enc.params["Cubemap_texture"].detach().cpu().numpy()
+    fail = enc.params["Cubemap_failv"].detach().cpu().numpy()
+    rin, rcm, rf = orc.cubemap_backward(w.t().contiguous().cpu().numpy(), d.detach().cpu().numpy(), tex, 1, 1)
+    assert rel_maxnorm(enc.params["Cubemap_texture"].grad.cpu().numpy(), rcm) <= 1e-5
+    assert rel_maxnorm(d.grad.cpu().numpy(), rin) <= 1e-4
+
+
+class _OracleCubemap(torch.autograd.Function):
+    """float64 CPU cubemap lookup through the oracle, as an autograd op (checker only)."""
+
+    @staticmethod
+    def forward(ctx, inputs, cubemap, fail):
+        from oracle import oracle as orc
+        out = orc.cubemap_forward(inputs.detach().numpy(), cubemap.detach().numpy(), fail.detach().numpy(), 1, 1, dtype=np.float64)
+        ctx.save_for_backward(inputs, cubemap)
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import oracle as orc
+        inputs, cubemap = ctx.saved_tensors
+        gin, gcm, gf = orc.cubemap_backward(g.contiguous().numpy(), inputs.detach().numpy(), cubemap.detach().numpy(), 1, 1, dtype=np.float64)
+        return torch.from_numpy(gin), torch.from_numpy(gcm), torch.from_numpy(gf)
+
+
+def _reference_chain(normal_view, base, strength, cubemap, fail, cam, W, H):
+    """gaussian_renderer/__init__.py:22-35,148,178-179,197-199 + utils/general_utils.py:177-197, float64 on the CPU."""
+    wvt = torch.from_numpy(cam["viewmatrix"]).double()
+    R = torch.from_numpy(cam["R"]).double()
+    T = torch.from_numpy(cam["T"]).double()
+    K = cam["K"].astype(np.float32)
+    rn = normal_view.permute(1, 2, 0) @ (wvt[:3, :3].T)
+    rn = rn / (torch.norm(rn, dim=-1, keepdim=True) + 1e-6)
+    Rw = R.T
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
+    pc = torch.tensor(np.dot(xy1, np.linalg.inv(K).T)).double()
+    rays_o = (-Rw.T @ T.unsqueeze(-1)).flatten()
+    pw = (pc - T[None, None]).reshape(-1, 3) @ Rw
+    rd = pw - rays_o[None]
+    rd = (rd / torch.norm(rd, dim=1, keepdim=True)).reshape(H, W, 3)
+    refl = rd - 2 * rn * torch.sum(rd * rn, dim=-1, keepdim=True)
+    col = torch.sigmoid(_OracleCubemap.apply(refl.reshape(-1, 3), cubemap, fail).permute(1, 0))
+    col = col.reshape(H, W, 3).permute(2, 0, 1)
+    final = (1 - strength) * base + strength * col
+    return final, col, rn.permute(2, 0, 1)
+
+
+def test_fused_deferred_reflection_vs_reference_chain():
+    from gaussian_renderer import deferred_reflection
+    W, H, L = 160, 96, 16
+    cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
+    g = torch.Generator().manual_seed(11)
+    nv = torch.randn(3, H, W, generator=g) * torch.rand(1, H, W, generator=g)
+    nv[:, :4, :4] = 0.0  # zero normals: r = d, exercises len = 0
+    base = torch.rand(3, H, W, generator=g)
+    strength = torch.rand(1, H, W, generator=g)
+    tex, fail = S.make_cubemap(L, 3, 4)
+    wf, wc, wn = torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g)
+
+    # reference chain, float64 CPU
+    leaf = lambda x: x.double().clone().requires_grad_(True)
+    nv_r, base_r, s_r, tex_r, fail_r = leaf(nv), leaf(base), leaf(strength), leaf(torch.from_numpy(tex)), leaf(torch.from_numpy(fail))
+    f_r, c_r, n_r = _reference_chain(nv_r, base_r, s_r, tex_r, fail_r, cam, W, H)
+    ((f_r * wf.double()).sum() + (c_r * wc.double()).sum() + (n_r * wn.double()).sum()).backward()
+
+    # fused HIP op
+    class Env:
+        pass
+    cu = lambda x: x.float().cuda().clone().requires_grad_(True)
+    nv_h, base_h, s_h, tex_h, fail_h = cu(nv), cu(base), cu(strength), cu(torch.from_numpy(tex)), cu(torch.from_numpy(fail))
+    env = Env()
+    env.params = {"Cubemap_texture": tex_h, "Cubemap_failv": fail_h}
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    f_h, c_h, n_h = deferred_reflection(nv_h, base_h, s_h, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+    ((f_h * wf.cuda()).sum() + (c_h * wc.cuda()).sum() + (n_h * wn.cuda()).sum()).backward()
+
+    # forward: texel selection is discontinuous in the direction at texel borders only through weights (continuous),
+    # so float32 vs float64 agree to rounding
+    np.testing.assert_allclose(f_h.detach().cpu().numpy(), f_r.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(c_h.detach().cpu().numpy(), c_r.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(n_h.detach().cpu().numpy(), n_r.detach().numpy(), atol=2e-5)
+    assert rel_maxnorm(base_h.grad.cpu().numpy(), base_r.grad.numpy()) <= 1e-5
+    assert rel_maxnorm(s_h.grad.cpu().numpy(), s_r.grad.numpy()) <= 1e-4
+    assert rel_maxnorm(tex_h.grad.cpu().numpy(), tex_r.grad.numpy()) <= 1e-4
+    # the normal gradient passes through d(texel weights)/d(direction), piecewise constant in the direction: pixels whose
+    # float32 direction lands in a different texel cell than the float64 one differ; allow a small budget of such pixels
+    gn_h, gn_r = nv_h.grad.cpu().numpy(), nv_r.grad.numpy()
+    bad = np.abs(gn_h - gn_r).max(axis=0) > 1e-3 * np.abs(gn_r).max()
+    assert bad.mean() <= 2e-3, bad.mean()
+
+
+def test_fused_matches_composed_hip_path():
+    """The fused kernel and the un-fused composition (torch ops + CubemapEncoder HIP kernels) must agree."""
+    from cubemapencoder import CubemapEncoder
+    from gaussian_renderer import deferred_reflection, get_refl_color
+    W, H, L = 200, 120, 32
+    cam = S.make_camera(W, H)
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    g = torch.Generator().manual_seed(2)
+    nv = torch.randn(3, H, W, generator=g).cuda()
+    base = torch.rand(3, H, W, generator=g).cuda()
+    s = torch.rand(1, H, W, generator=g).cuda()
+    enc = CubemapEncoder(output_dim=3, resolution=L).cuda()
+    f_h, c_h, n_h = deferred_reflection(nv, base, s, enc, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+    rn = (nv.permute(1, 2, 0) @ (ct["viewmatrix"][:3, :3].T))
+    rn = rn / (torch.norm(rn, dim=-1, keepdim=True) + 1e-6)
+    c_c = get_refl_color(enc, (H, W, cam["K"]), ct["R"], ct["T"], rn)
+    f_c = (1 - s) * base + s * c_c
+    # float32 on both sides; a direction a few ulps apart may pick neighbouring texel weights: tolerance, not bit equality
+    assert (torch.abs(f_h - f_c) > 1e-3).float().mean().item() <= 1e-3
+    assert (torch.abs(n_h - rn.permute(2, 0, 1)) > 1e-5).float().mean().item() == 0.0

@@ -139,13 +139,13 @@ def test_cull_is_bit_exact(variant):
         try:
             if variant == "S":
                 hip = HipSurfel(kw)
-                out = hip.out()
+                out, nc, ft = hip.out(), hip.state("n_contrib"), hip.state("final_T")
                 gh = hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
             else:
                 hip = HipGauss(kw, antialiasing=True)
-                out = hip.out()
+                out, nc, ft = hip.out(), hip.state("n_contrib"), hip.state("final_T")
                 gh = hip.backward(g["dL_dcolor"], g["dL_dinvdepth"], g["dL_dnormal"], g["dL_drefl"])
-            res.append((out, gh, hip.state("n_contrib"), hip.state("final_T")))
+            res.append((out, gh, nc, ft))
         finally:
             _gsr.set_option("cull", 1)
     (o0, g0, n0, t0), (o1, g1, n1, t1) = res
