@@ -403,198 +403,227 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 	}
 }
 
-// renderCUDA backward (DSR backward.cu:143-470).  ~19 atomics per pair in the reference; here: DPP wave
-// reduction -> per-wave LDS slab -> one 80-byte row of float atomics per (tile, surfel) into acc[P][20].
-#define S_BWD_BATCH 64
-__global__ void __launch_bounds__(256)
-surfel_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                         const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
-                         int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                         const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
-	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-	if (tile >= (uint32_t)ntiles) return;
+// ---------------------------------------------------------------------------------------------------
+// renderCUDA backward (DSR backward.cu:143-470).
+// Per-pixel recursion state of the back-to-front traversal + this pixel's upstream gradients.
+struct SurfelBwdPix {
+	float T, T_final, final_D, final_D2, final_A, last_dL_dT, bg_dot_dpixel;
+	int last_contributor, median_contributor;
+	float dp0, dp1, dp2, dr, dL_dreg, dL_ddepth, dL_daccum, dnx, dny, dnz, dL_dmedian_depth;
+	float acc_c0, acc_c1, acc_c2, acc_r, acc_depth, acc_alpha, acc_n0, acc_n1, acc_n2;
+	float last_alpha, lc0, lc1, lc2, lr, last_depth, ln0, ln1, ln2;
+};
+__device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, size_t pix, size_t HW, const float* __restrict__ bg,
+                                                const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                                                const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
+                                                const float* __restrict__ dL_drefl_map) {
+	s.T_final = inside ? final_Ts[pix] : 0.f;
+	s.T = s.T_final;
+	s.last_contributor = inside ? (int)n_contrib[pix] : 0;
+	s.median_contributor = inside ? (int)n_contrib[HW + pix] : 0;
+	s.dp0 = s.dp1 = s.dp2 = s.dr = 0.f;
+	s.dL_dreg = s.dL_ddepth = s.dL_daccum = s.dnx = s.dny = s.dnz = s.dL_dmedian_depth = 0.f;
+	if (inside) {
+		s.dp0 = dL_dpixels[pix]; s.dp1 = dL_dpixels[HW + pix]; s.dp2 = dL_dpixels[2 * HW + pix];
+		s.dr = dL_drefl_map[pix];
+		s.dL_ddepth = dL_depths[0 * HW + pix];
+		s.dL_daccum = dL_depths[1 * HW + pix];
+		s.dnx = dL_depths[2 * HW + pix]; s.dny = dL_depths[3 * HW + pix]; s.dnz = dL_depths[4 * HW + pix];
+		s.dL_dmedian_depth = dL_depths[5 * HW + pix];
+		s.dL_dreg = dL_depths[6 * HW + pix];
+	}
+	s.final_D = inside ? final_Ts[HW + pix] : 0.f;
+	s.final_D2 = inside ? final_Ts[2 * HW + pix] : 0.f;
+	s.final_A = 1 - s.T_final;
+	s.last_dL_dT = 0;
+	s.acc_c0 = s.acc_c1 = s.acc_c2 = s.acc_r = s.acc_depth = s.acc_alpha = s.acc_n0 = s.acc_n1 = s.acc_n2 = 0.f;
+	s.last_alpha = s.lc0 = s.lc1 = s.lc2 = s.lr = s.last_depth = s.ln0 = s.ln1 = s.ln2 = 0.f;
+	s.bg_dot_dpixel = bg[0] * s.dp0 + bg[1] * s.dp1 + bg[2] * s.dp2;
+}
+// One contributing (pixel, surfel) pair: advances the recursion and writes the 19 gradient contributions
+// (slots SA_*) into v.  Text follows DSR backward.cu:338-467.
+__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, const float4 r2, const float4 r3, const float4 r4,
+                                                int contributor, float pixx, float pixy, float* v) {
+	const float alpha = o.alpha, G = o.G, c_d = o.depth;
+	const float Twx = r2.x, Twy = r2.y;
+	s.T = s.T / (1.f - alpha);
+	const float T = s.T;
+	const float dchannel_dcolor = alpha * T;
+	const float last_alpha = s.last_alpha;
+	float dL_dalpha = 0.0f;
+	s.acc_c0 = last_alpha * s.lc0 + (1.f - last_alpha) * s.acc_c0; s.lc0 = r3.w; dL_dalpha += (r3.w - s.acc_c0) * s.dp0;
+	s.acc_c1 = last_alpha * s.lc1 + (1.f - last_alpha) * s.acc_c1; s.lc1 = r4.x; dL_dalpha += (r4.x - s.acc_c1) * s.dp1;
+	s.acc_c2 = last_alpha * s.lc2 + (1.f - last_alpha) * s.acc_c2; s.lc2 = r4.y; dL_dalpha += (r4.y - s.acc_c2) * s.dp2;
+	v[SA_COLOR + 0] = dchannel_dcolor * s.dp0;
+	v[SA_COLOR + 1] = dchannel_dcolor * s.dp1;
+	v[SA_COLOR + 2] = dchannel_dcolor * s.dp2;
+	s.acc_r = last_alpha * s.lr + (1.f - last_alpha) * s.acc_r; s.lr = r4.z;
+	dL_dalpha += (r4.z - s.acc_r) * s.dr;
+	v[SA_REFL] = dchannel_dcolor * s.dr;
+	float dL_dz = 0.0f, dL_dweight = 0.f;
+	const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(c_d));
+	const float dmd_dd = (S_FAR * S_NEAR) / ((S_FAR - S_NEAR) * c_d * c_d);
+	if (contributor == s.median_contributor - 1) dL_dz += s.dL_dmedian_depth;
+	dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2 * m_d * s.final_D) * s.dL_dreg;
+	dL_dalpha += dL_dweight - s.last_dL_dT;
+	s.last_dL_dT = dL_dweight * alpha + (1 - alpha) * s.last_dL_dT;
+	const float dL_dmd = 2.0f * (T * alpha) * (m_d * s.final_A - s.final_D) * s.dL_dreg;
+	dL_dz += dL_dmd * dmd_dd;
+	s.acc_depth = last_alpha * s.last_depth + (1.f - last_alpha) * s.acc_depth; s.last_depth = c_d;
+	dL_dalpha += (c_d - s.acc_depth) * s.dL_ddepth;
+	s.acc_alpha = last_alpha * 1.0f + (1.f - last_alpha) * s.acc_alpha;
+	dL_dalpha += (1 - s.acc_alpha) * s.dL_daccum;
+	s.acc_n0 = last_alpha * s.ln0 + (1.f - last_alpha) * s.acc_n0; s.ln0 = r2.w; dL_dalpha += (r2.w - s.acc_n0) * s.dnx;
+	s.acc_n1 = last_alpha * s.ln1 + (1.f - last_alpha) * s.acc_n1; s.ln1 = r3.x; dL_dalpha += (r3.x - s.acc_n1) * s.dny;
+	s.acc_n2 = last_alpha * s.ln2 + (1.f - last_alpha) * s.acc_n2; s.ln2 = r3.y; dL_dalpha += (r3.y - s.acc_n2) * s.dnz;
+	v[SA_NORMAL + 0] = alpha * T * s.dnx;
+	v[SA_NORMAL + 1] = alpha * T * s.dny;
+	v[SA_NORMAL + 2] = alpha * T * s.dnz;
+	dL_dalpha *= T;
+	s.last_alpha = alpha;
+	dL_dalpha += (-s.T_final / (1.f - alpha)) * s.bg_dot_dpixel;
+	const float dL_dG = r3.z * dL_dalpha;
+	dL_dz += alpha * T * s.dL_ddepth;
+	if (o.rho3d <= o.rho2d) {
+		const float dL_dsx = dL_dG * -G * o.sx + dL_dz * Twx;
+		const float dL_dsy = dL_dG * -G * o.sy + dL_dz * Twy;
+		const float dsx_pz = dL_dsx / o.pz, dsy_pz = dL_dsy / o.pz;
+		const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * o.sx + dsy_pz * o.sy);
+		// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
+		const float dkx = o.ly * dpz - o.lz * dpy, dky = o.lz * dpx - o.lx * dpz, dkz = o.lx * dpy - o.ly * dpx;
+		const float dlx = dpy * o.kz - dpz * o.ky, dly = dpz * o.kx - dpx * o.kz, dlz = dpx * o.ky - dpy * o.kx;
+		v[SA_T + 0] = -dkx; v[SA_T + 1] = -dky; v[SA_T + 2] = -dkz;
+		v[SA_T + 3] = -dlx; v[SA_T + 4] = -dly; v[SA_T + 5] = -dlz;
+		v[SA_T + 6] = pixx * dkx + pixy * dlx + dL_dz * o.sx;
+		v[SA_T + 7] = pixx * dky + pixy * dly + dL_dz * o.sy;
+		v[SA_T + 8] = pixx * dkz + pixy * dlz + dL_dz * 1.0f;
+	} else {
+		const float dG_ddelx = -G * S_FILTER_INV_SQ * o.dx;
+		const float dG_ddely = -G * S_FILTER_INV_SQ * o.dy;
+		v[SA_MEAN2D + 0] = dL_dG * dG_ddelx;
+		v[SA_MEAN2D + 1] = dL_dG * dG_ddely;
+		v[SA_T + 6] = o.sx * dL_dz;
+		v[SA_T + 7] = o.sy * dL_dz;
+		v[SA_T + 8] = dL_dz;
+	}
+	v[SA_OPAC] = G * dL_dalpha;
+}
+
+// Wave-per-quadrant backward.  One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a tile and
+// walks the tile's list back to front in batches of 64 entries:
+//   1. each lane takes one list entry, loads its bounds and votes (ballot) whether the surfel can reach
+//      this block and is before the wave's last contributor -> compacted private work list;
+//   2. only the surviving records are gathered (5 lanes per 80-byte record) into LDS;
+//   3. the wave blends the survivors; per contributing surfel the 19 gradient values are reduced across
+//      the 64 pixels with fused DPP adds and parked in LDS by lane 63;
+//   4. the wave flushes the parked rows as 80-byte contiguous float atomics into acc[P][20].
+// No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
+// threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
+#define S_WBATCH 64
+__global__ void __launch_bounds__(64)
+surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
+                              int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                              const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
+                              float* __restrict__ acc) {
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, contiguous per XCD
+	if (unit >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const int lane = threadIdx.x;
+	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
+	if (bx0 >= W || by0 >= H) return;
+	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixx = (float)px, pixy = (float)py;
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
 	const size_t HW = (size_t)H * W;
 	const size_t pix = (size_t)W * py + px;
+	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float4 s_rec[S_BWD_BATCH * S_REC_F4];
-	__shared__ float4 s_bbox[S_BWD_BATCH];
-	__shared__ uint32_t s_id[S_BWD_BATCH];
-	__shared__ float4 s_slab[4][S_BWD_BATCH][S_ACC_F / 4];
-	__shared__ unsigned long long s_touched[4];
-	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
-	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
+	__shared__ float4 s_rec[S_WBATCH * S_REC_F4];
+	__shared__ float4 s_slab[S_WBATCH * (S_ACC_F / 4)];
+	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
+	__shared__ uint8_t s_hj[S_WBATCH];     // its position inside the batch
 
-	const float T_final = inside ? final_Ts[pix] : 0.f;
-	float T = T_final;
-	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-	const int median_contributor = inside ? (int)n_contrib[HW + pix] : 0;
-	float dp0 = 0, dp1 = 0, dp2 = 0, dr = 0;
-	float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dnx = 0, dny = 0, dnz = 0, dL_dmedian_depth = 0;
-	if (inside) {
-		dp0 = dL_dpixels[pix]; dp1 = dL_dpixels[HW + pix]; dp2 = dL_dpixels[2 * HW + pix];
-		dr = dL_drefl_map[pix];
-		dL_ddepth = dL_depths[0 * HW + pix];
-		dL_daccum = dL_depths[1 * HW + pix];
-		dnx = dL_depths[2 * HW + pix]; dny = dL_depths[3 * HW + pix]; dnz = dL_depths[4 * HW + pix];
-		dL_dmedian_depth = dL_depths[5 * HW + pix];
-		dL_dreg = dL_depths[6 * HW + pix];
-	}
-	const float final_D = inside ? final_Ts[HW + pix] : 0.f;
-	const float final_D2 = inside ? final_Ts[2 * HW + pix] : 0.f;
-	const float final_A = 1 - T_final;
-	float last_dL_dT = 0;
-	float acc_c0 = 0, acc_c1 = 0, acc_c2 = 0, acc_r = 0, acc_depth = 0, acc_alpha = 0, acc_n0 = 0, acc_n1 = 0, acc_n2 = 0;
-	float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, lr = 0, last_depth = 0, ln0 = 0, ln1 = 0, ln2 = 0;
-	const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+	SurfelBwdPix st;
+	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
+	// entries at or beyond the furthest last-contributor of the 64 pixels can be dropped for the whole wave
+	int wave_last = st.last_contributor;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+	if (wave_last == 0) return;
 
-	for (int base = 0; base < count; base += S_BWD_BATCH) {
-		const int nb = min(S_BWD_BATCH, count - base);
-		__syncthreads();
-		for (int item = tid; item < nb * S_REC_F4; item += 256) {
-			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
-			const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
-			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
-		}
-		if (tid < nb) {
-			const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + tid)];
-			s_id[tid] = id;
-			s_bbox[tid] = bbox[id];
-		}
-		__syncthreads();
-		unsigned long long touched = 0ull;
-		// per-wave culling: ballot of "bounds reach my 8x8 pixels AND someone in the wave still has this entry
-		// before its last contributor"; walk the set bits only
-		unsigned long long mm;
-		{
-			bool hit = lane < nb;
-			if (hit && cull) {
-				const float4 bb = s_bbox[lane];
+	// skip the batches that lie entirely beyond wave_last (list is walked back to front)
+	const int first = max(0, count - wave_last);
+	for (int base = (first / S_WBATCH) * S_WBATCH; base < count; base += S_WBATCH) {
+		const int nb = min(S_WBATCH, count - base);
+		// ---- 1. vote
+		bool hit = lane < nb && (count - 1 - (base + lane)) < wave_last;
+		uint32_t id = 0;
+		if (hit) {
+			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
+			if (cull) {
+				const float4 bb = bbox[id];
 				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 			}
-			mm = __ballot(hit);
 		}
-		while (mm != 0ull) {
-			const int j = (int)__builtin_ctzll(mm);
-			mm &= mm - 1ull;
-			const int contributor = count - 1 - (base + j);
-			const float4 r0 = s_rec[j * S_REC_F4 + 0];
-			const float4 r1 = s_rec[j * S_REC_F4 + 1];
-			const float4 r2 = s_rec[j * S_REC_F4 + 2];
-			const float4 r3 = s_rec[j * S_REC_F4 + 3];
+		const unsigned long long mm = __ballot(hit);
+		const int nh = __popcll(mm);
+		if (nh == 0) continue;
+		// ---- 2. compact + gather
+		if (hit) {
+			const int k = __popcll(mm & ((1ull << lane) - 1ull));
+			s_hid[k] = id;
+			s_hj[k] = (uint8_t)lane;
+		}
+		__syncthreads();
+		for (int item = lane; item < nh * S_REC_F4; item += 64) {
+			const int k = item / S_REC_F4, q = item - k * S_REC_F4;
+			s_rec[item] = rec[(size_t)s_hid[k] * S_REC_F4 + q];
+		}
+		__syncthreads();
+		// ---- 3. blend the survivors (all lanes stay converged: k is wave-uniform)
+		unsigned long long touched = 0ull;
+		for (int k = 0; k < nh; k++) {
+			const int contributor = count - 1 - (base + (int)s_hj[k]);
+			const float4 r0 = s_rec[k * S_REC_F4 + 0];
+			const float4 r1 = s_rec[k * S_REC_F4 + 1];
+			const float4 r2 = s_rec[k * S_REC_F4 + 2];
+			const float4 r3 = s_rec[k * S_REC_F4 + 3];
 			SurfelPair o;
-			const bool ok = inside && contributor < last_contributor && surfel_pair<false>(r0, r1, r2, r3.z, pixx, pixy, o);
+			const bool ok = inside && contributor < st.last_contributor && surfel_pair<false>(r0, r1, r2, r3.z, pixx, pixy, o);
 			if (__ballot(ok) == 0ull) continue;
-			const float4 r4 = s_rec[j * S_REC_F4 + 4];
+			const float4 r4 = s_rec[k * S_REC_F4 + 4];
 			float v[S_ACC_F];
 #pragma unroll
 			for (int q = 0; q < S_ACC_F; q++) v[q] = 0.f;
-			if (ok) {
-				const float alpha = o.alpha, G = o.G, c_d = o.depth;
-				const float Twx = r2.x, Twy = r2.y;
-				T = T / (1.f - alpha);
-				const float dchannel_dcolor = alpha * T;
-				float dL_dalpha = 0.0f;
-				acc_c0 = last_alpha * lc0 + (1.f - last_alpha) * acc_c0; lc0 = r3.w; dL_dalpha += (r3.w - acc_c0) * dp0;
-				acc_c1 = last_alpha * lc1 + (1.f - last_alpha) * acc_c1; lc1 = r4.x; dL_dalpha += (r4.x - acc_c1) * dp1;
-				acc_c2 = last_alpha * lc2 + (1.f - last_alpha) * acc_c2; lc2 = r4.y; dL_dalpha += (r4.y - acc_c2) * dp2;
-				v[SA_COLOR + 0] = dchannel_dcolor * dp0;
-				v[SA_COLOR + 1] = dchannel_dcolor * dp1;
-				v[SA_COLOR + 2] = dchannel_dcolor * dp2;
-				acc_r = last_alpha * lr + (1.f - last_alpha) * acc_r; lr = r4.z;
-				dL_dalpha += (r4.z - acc_r) * dr;
-				v[SA_REFL] = dchannel_dcolor * dr;
-				float dL_dz = 0.0f, dL_dweight = 0.f;
-				const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(c_d));
-				const float dmd_dd = (S_FAR * S_NEAR) / ((S_FAR - S_NEAR) * c_d * c_d);
-				if (contributor == median_contributor - 1) dL_dz += dL_dmedian_depth;
-				dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-				dL_dalpha += dL_dweight - last_dL_dT;
-				last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-				const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-				dL_dz += dL_dmd * dmd_dd;
-				acc_depth = last_alpha * last_depth + (1.f - last_alpha) * acc_depth; last_depth = c_d;
-				dL_dalpha += (c_d - acc_depth) * dL_ddepth;
-				acc_alpha = last_alpha * 1.0f + (1.f - last_alpha) * acc_alpha;
-				dL_dalpha += (1 - acc_alpha) * dL_daccum;
-				acc_n0 = last_alpha * ln0 + (1.f - last_alpha) * acc_n0; ln0 = r2.w; dL_dalpha += (r2.w - acc_n0) * dnx;
-				acc_n1 = last_alpha * ln1 + (1.f - last_alpha) * acc_n1; ln1 = r3.x; dL_dalpha += (r3.x - acc_n1) * dny;
-				acc_n2 = last_alpha * ln2 + (1.f - last_alpha) * acc_n2; ln2 = r3.y; dL_dalpha += (r3.y - acc_n2) * dnz;
-				v[SA_NORMAL + 0] = alpha * T * dnx;
-				v[SA_NORMAL + 1] = alpha * T * dny;
-				v[SA_NORMAL + 2] = alpha * T * dnz;
-				dL_dalpha *= T;
-				last_alpha = alpha;
-				dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-				const float dL_dG = r3.z * dL_dalpha;
-				dL_dz += alpha * T * dL_ddepth;
-				if (o.rho3d <= o.rho2d) {
-					const float dL_dsx = dL_dG * -G * o.sx + dL_dz * Twx;
-					const float dL_dsy = dL_dG * -G * o.sy + dL_dz * Twy;
-					const float dsx_pz = dL_dsx / o.pz, dsy_pz = dL_dsy / o.pz;
-					const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * o.sx + dsy_pz * o.sy);
-					// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
-					const float dkx = o.ly * dpz - o.lz * dpy, dky = o.lz * dpx - o.lx * dpz, dkz = o.lx * dpy - o.ly * dpx;
-					const float dlx = dpy * o.kz - dpz * o.ky, dly = dpz * o.kx - dpx * o.kz, dlz = dpx * o.ky - dpy * o.kx;
-					v[SA_T + 0] = -dkx; v[SA_T + 1] = -dky; v[SA_T + 2] = -dkz;
-					v[SA_T + 3] = -dlx; v[SA_T + 4] = -dly; v[SA_T + 5] = -dlz;
-					v[SA_T + 6] = pixx * dkx + pixy * dlx + dL_dz * o.sx;
-					v[SA_T + 7] = pixx * dky + pixy * dly + dL_dz * o.sy;
-					v[SA_T + 8] = pixx * dkz + pixy * dlz + dL_dz * 1.0f;
-				} else {
-					const float dG_ddelx = -G * S_FILTER_INV_SQ * o.dx;
-					const float dG_ddely = -G * S_FILTER_INV_SQ * o.dy;
-					v[SA_MEAN2D + 0] = dL_dG * dG_ddelx;
-					v[SA_MEAN2D + 1] = dL_dG * dG_ddely;
-					v[SA_T + 6] = o.sx * dL_dz;
-					v[SA_T + 7] = o.sy * dL_dz;
-					v[SA_T + 8] = dL_dz;
-				}
-				v[SA_OPAC] = G * dL_dalpha;
-			}
+			if (ok) surfel_bwd_pair(st, o, r2, r3, r4, contributor, pixx, pixy, v);
 			if (!(dev_flags & 2)) {
 				wave_sum8(v);
 				wave_sum8(v + 8);
 				wave_sum4(v + 16);
 			}
 			if (lane == 63) {
-				s_slab[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
-				s_slab[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
-				s_slab[wave][j][2] = make_float4(v[8], v[9], v[10], v[11]);
-				s_slab[wave][j][3] = make_float4(v[12], v[13], v[14], v[15]);
-				s_slab[wave][j][4] = make_float4(v[16], v[17], v[18], 0.f);
+				s_slab[k * 5 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+				s_slab[k * 5 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+				s_slab[k * 5 + 2] = make_float4(v[8], v[9], v[10], v[11]);
+				s_slab[k * 5 + 3] = make_float4(v[12], v[13], v[14], v[15]);
+				s_slab[k * 5 + 4] = make_float4(v[16], v[17], v[18], 0.f);
 			}
-			touched |= 1ull << j;
+			touched |= 1ull << k;
 		}
-		if (lane == 0) s_touched[wave] = touched;
 		__syncthreads();
-		for (int item = tid; item < nb * (S_ACC_F / 4); item += 256) {
-			const int i = item / (S_ACC_F / 4), q = item - i * (S_ACC_F / 4);
-			float4 s = make_float4(0, 0, 0, 0);
-			bool any = false;
-#pragma unroll
-			for (int w = 0; w < 4; w++) {
-				if ((s_touched[w] >> i) & 1ull) {
-					const float4 t = s_slab[w][i][q];
-					s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-					any = true;
-				}
-			}
-			if (any && !(dev_flags & 1)) {
-				float* dst = acc + (size_t)s_id[i] * S_ACC_F + q * 4;
-				atomicAdd(dst + 0, s.x);
-				atomicAdd(dst + 1, s.y);
-				atomicAdd(dst + 2, s.z);
-				if (q != 4) atomicAdd(dst + 3, s.w);
+		// ---- 4. flush: lane -> (hit k, float d); 80 contiguous bytes per surfel
+		if (touched != 0ull && !(dev_flags & 1)) {
+			const float* slab = reinterpret_cast<const float*>(s_slab);
+			for (int item = lane; item < nh * S_ACC_F; item += 64) {
+				const int k = item / S_ACC_F, d = item - k * S_ACC_F;
+				if (d < S_ACC_F - 1 && ((touched >> k) & 1ull)) atomicAdd(acc + (size_t)s_hid[k] * S_ACC_F + d, slab[item]);
 			}
 		}
+		__syncthreads();
 	}
 }
 
@@ -844,9 +873,11 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
 	if (R > 0) {
 		const int nblocks = ((ntiles + 7) / 8) * 8;
-{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); 		surfel_render_bwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-		                                                      geom.bbox, option_cull(), option_dev(),
-		                                                      img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
+{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
+		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+		surfel_render_bwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+		                                                         geom.bbox, option_cull(), option_dev(), img.final_T, img.n_contrib, dL_dpix,
+		                                                         dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
