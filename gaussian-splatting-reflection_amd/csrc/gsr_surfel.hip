@@ -520,8 +520,8 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 // No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
 // threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
 #define S_WBATCH 64
-__global__ void __launch_bounds__(64)
-surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+__device__ __forceinline__ void
+surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
                               int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                               const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
@@ -542,10 +542,9 @@ surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 	const size_t pix = (size_t)W * py + px;
 	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float4 s_rec[S_WBATCH * S_REC_F4];
 	__shared__ float4 s_slab[S_WBATCH * (S_ACC_F / 4)];
 	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
-	__shared__ uint8_t s_hj[S_WBATCH];     // its position inside the batch
+	__shared__ uint32_t s_hj[S_WBATCH];    // its position inside the batch
 
 	SurfelBwdPix st;
 	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
@@ -572,45 +571,45 @@ surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
-		// ---- 2. compact + gather
+		// ---- 2. compact: lane k ends up holding the id / batch position of the k-th surviving entry
 		if (hit) {
 			const int k = __popcll(mm & ((1ull << lane) - 1ull));
 			s_hid[k] = id;
-			s_hj[k] = (uint8_t)lane;
+			s_hj[k] = (uint32_t)lane;
 		}
 		__syncthreads();
-		for (int item = lane; item < nh * S_REC_F4; item += 64) {
-			const int k = item / S_REC_F4, q = item - k * S_REC_F4;
-			s_rec[item] = rec[(size_t)s_hid[k] * S_REC_F4 + q];
-		}
-		__syncthreads();
-		// ---- 3. blend the survivors (all lanes stay converged: k is wave-uniform)
+		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
+		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
+		// ---- 3. blend the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
+		// (v_readlane) and the 80-byte record comes in through the SCALAR memory path (s_load_dwordx4) into SGPRs:
+		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
+		// current one is being differentiated.
 		unsigned long long touched = 0ull;
+		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * S_REC_F4;
+		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3], n4 = rp[4];
 		for (int k = 0; k < nh; k++) {
-			const int contributor = count - 1 - (base + (int)s_hj[k]);
-			const float4 r0 = s_rec[k * S_REC_F4 + 0];
-			const float4 r1 = s_rec[k * S_REC_F4 + 1];
-			const float4 r2 = s_rec[k * S_REC_F4 + 2];
-			const float4 r3 = s_rec[k * S_REC_F4 + 3];
+			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4;
+			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			SurfelPair o;
 			const bool ok = inside && contributor < st.last_contributor && surfel_pair<false>(r0, r1, r2, r3.z, pixx, pixy, o);
+			if (k + 1 < nh) {
+				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * S_REC_F4;
+				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+			}
 			if (__ballot(ok) == 0ull) continue;
-			const float4 r4 = s_rec[k * S_REC_F4 + 4];
 			float v[S_ACC_F];
 #pragma unroll
 			for (int q = 0; q < S_ACC_F; q++) v[q] = 0.f;
 			if (ok) surfel_bwd_pair(st, o, r2, r3, r4, contributor, pixx, pixy, v);
-			if (!(dev_flags & 2)) {
-				wave_sum8(v);
-				wave_sum8(v + 8);
-				wave_sum4(v + 16);
-			}
-			if (lane == 63) {
-				s_slab[k * 5 + 0] = make_float4(v[0], v[1], v[2], v[3]);
-				s_slab[k * 5 + 1] = make_float4(v[4], v[5], v[6], v[7]);
-				s_slab[k * 5 + 2] = make_float4(v[8], v[9], v[10], v[11]);
-				s_slab[k * 5 + 3] = make_float4(v[12], v[13], v[14], v[15]);
-				s_slab[k * 5 + 4] = make_float4(v[16], v[17], v[18], 0.f);
+			// 20 values -> 5 registers of 4 folded values -> row sums; lanes 15/31/47/63 park one value each
+			float z[5];
+#pragma unroll
+			for (int g = 0; g < 5; g++) z[g] = fold4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+			row_sum5(z);
+			if ((lane & 15) == 15) {
+				float* slab = reinterpret_cast<float*>(s_slab) + k * S_ACC_F + fold_slot(lane);
+#pragma unroll
+				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
 			}
 			touched |= 1ull << k;
 		}
@@ -626,6 +625,20 @@ surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		__syncthreads();
 	}
 }
+
+#define GSR_DEF_SURFEL_BWD_WAVE(NAME, WPE)                                                                                                  \
+	__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                                                     \
+	NAME(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,                   \
+	     const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,             \
+	     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,                   \
+	     const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {                             \
+		surfel_render_bwd_wave_body(ranges, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib,          \
+		                            dL_dpixels, dL_depths, dL_drefl_map, acc);                                                               \
+	}
+GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w3, 3)
+GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w4, 4)
+GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w5, 5)
+GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w6, 6)
 
 // quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
 __device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, const M3& v_R, float* v_quat) {
@@ -875,9 +888,11 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
-		surfel_render_bwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-		                                                         geom.bbox, option_cull(), option_dev(), img.final_T, img.n_contrib, dL_dpix,
-		                                                         dL_dothers, dL_drefl_strength_map, geom.acc); }
+		const int wpe = (option_dev() >> 4) & 15;
+		auto kern = wpe == 3 ? surfel_render_bwd_wave_kernel_w3 : wpe == 5 ? surfel_render_bwd_wave_kernel_w5
+		          : wpe == 6 ? surfel_render_bwd_wave_kernel_w6 : surfel_render_bwd_wave_kernel_w4;
+		kern<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
+		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
