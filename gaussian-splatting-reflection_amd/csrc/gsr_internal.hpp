@@ -218,6 +218,18 @@ __device__ __forceinline__ float wave_max_pos(float v) {  // max over lanes of n
 	return v;
 }
 
+
+// a / b with one Newton-Raphson correction on v_rcp_f32: correctly rounded except in rare last-bit cases,
+// ~8 ns per wave instead of ~18 ns for the IEEE v_div_scale/v_div_fmas/v_div_fixup sequence (measured,
+// tests/microbench/valu_rate.hip).  Only for operands known to be finite, normal and far from overflow
+// (1 - alpha >= 0.01, |p.z| >= 1e-6, depth >= 0.2 in the tile kernels).
+__device__ __forceinline__ float div_nr(float a, float b) {
+	const float r = __builtin_amdgcn_rcpf(b);
+	const float q = a * r;
+	const float e = fmaf(-b, q, a);
+	return fmaf(e, r, q);
+}
+
 // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so
 // give each XCD a contiguous band of tiles (neighbouring tiles gather the same Gaussian records and
 // then hit the same L2).  Pure performance; any mapping is correct.

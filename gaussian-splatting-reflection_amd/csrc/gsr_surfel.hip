@@ -230,7 +230,7 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	o.pz = o.kx * o.ly - o.ky * o.lx;
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
 	if (!unstable) {
-		const float inv_pz = 1.0f / o.pz;  // IEEE division: the backward is ill-conditioned enough that a 1-ulp rcp costs 1e-4 in dL_dscale
+		const float inv_pz = div_nr(1.0f, o.pz);  // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale: the backward is ill-conditioned)
 		o.sx = ppx * inv_pz;
 		o.sy = ppy * inv_pz;
 	} else {
@@ -251,32 +251,37 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	return !(o.alpha < 1.0f / 255.0f);
 }
 
-// renderCUDA forward (DSR forward.cu:258-489)
-__global__ void __launch_bounds__(256)
-surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                         const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
-                         float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                         float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
-	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-	if (tile >= (uint32_t)ntiles) return;
+// renderCUDA forward (DSR forward.cu:258-489), wave-per-quadrant form.
+// One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a 16x16 tile and walks the tile's list front
+// to back in batches of 64 entries: (1) every lane takes one entry, loads its conservative bounds and votes
+// (ballot) whether it can reach this block -> private compacted work list; (2) the wave blends the survivors,
+// pulling each 80-byte record through the scalar memory path into SGPRs (it is wave-uniform) while the
+// previous one is still being blended; (3) the per-surfel max blend weight goes out with one atomic per
+// touched surfel.  The wave stops as soon as ITS 64 pixels are saturated: no workgroup barriers, no waiting
+// for the other three quadrants (the reference synchronises the 256 threads of a tile twice per batch).
+#define S_WBATCH 64
+__global__ void __launch_bounds__(64)
+surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                              const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
+                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                              float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, contiguous per XCD
+	if (unit >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const int lane = threadIdx.x;
+	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
+	if (bx0 >= W || by0 >= H) return;
+	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixx = (float)px, pixy = (float)py;
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
+	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	constexpr int BATCH = 128;
-	__shared__ float4 s_rec[BATCH * S_REC_F4];   // 10 KB
-	__shared__ float4 s_bbox[BATCH];
-	__shared__ uint32_t s_id[BATCH];
-	__shared__ float s_wmax[4][BATCH];           // per-wave max blend weight of this batch
-	__shared__ int s_done[4];
-	// pixel bounds of this wave's 8x8 quadrant (for the per-wave culling)
-	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
-	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
+	__shared__ uint32_t s_hid[S_WBATCH];
+	__shared__ uint32_t s_hj[S_WBATCH];
+	__shared__ float s_wmax[S_WBATCH];
 
 	bool done = !inside;
 	float T = 1.0f;
@@ -285,100 +290,88 @@ surfel_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __res
 	float N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
 	float median_contributor = -1.0f;
 
-	for (int base = 0; base < count; base += BATCH) {
-		const bool wave_done = __ballot(!done) == 0ull;
-		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
-		__syncthreads();  // also: previous batch's s_wmax flush finished
-		if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == 4) break;
-		const int nb = min(BATCH, count - base);
-		for (int item = tid; item < nb * S_REC_F4; item += 256) {
-			const int i = item / S_REC_F4, q = item - i * S_REC_F4;
-			const uint32_t id = point_list[range.x + base + i];
-			s_rec[item] = rec[(size_t)id * S_REC_F4 + q];
-		}
-		if (tid < BATCH) {
-			if (tid < nb) {
-				const uint32_t id = point_list[range.x + base + tid];
-				s_id[tid] = id;
-				s_bbox[tid] = bbox[id];
+	for (int base = 0; base < count; base += S_WBATCH) {
+		if (__ballot(!done) == 0ull) break;
+		const int nb = min(S_WBATCH, count - base);
+		// ---- 1. vote
+		bool hit = lane < nb;
+		uint32_t id = 0;
+		if (hit) {
+			id = point_list[range.x + (uint32_t)(base + lane)];
+			if (cull) {
+				const float4 bb = bbox[id];
+				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 			}
-			s_wmax[0][tid] = 0.f; s_wmax[1][tid] = 0.f; s_wmax[2][tid] = 0.f; s_wmax[3][tid] = 0.f;
+		}
+		const unsigned long long mm = __ballot(hit);
+		const int nh = __popcll(mm);
+		if (nh == 0) continue;
+		if (hit) {
+			const int k = __popcll(mm & ((1ull << lane) - 1ull));
+			s_hid[k] = id;
+			s_hj[k] = (uint32_t)lane;
 		}
 		__syncthreads();
-		if (!wave_done) {
-			// Per-wave key compaction: one ballot per 64 entries marks the Gaussians whose conservative bounds
-			// reach this wave's 8x8 pixels; the wave then walks only the set bits (scalar s_ff1), so culled
-			// entries cost nothing in the blend loop.
-			unsigned long long hits[BATCH / 64];
-#pragma unroll
-			for (int h = 0; h < BATCH / 64; h++) {
-				const int e = h * 64 + lane;
-				bool hit = e < nb;
-				if (hit && cull) {
-					const float4 bb = s_bbox[e];
-					hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
-				}
-				hits[h] = __ballot(hit);
+		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
+		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
+		// ---- 2. blend
+		unsigned long long touched = 0ull;
+		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * S_REC_F4;
+		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3], n4 = rp[4];
+		for (int k = 0; k < nh; k++) {
+			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4;
+			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
+			SurfelPair o;
+			bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
+			if (k + 1 < nh) {
+				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * S_REC_F4;
+				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
 			}
-			bool all_done = false;
-#pragma unroll
-			for (int h = 0; h < BATCH / 64; h++) {
-				unsigned long long mm = hits[h];
-				while (mm != 0ull && !all_done) {
-					const int j = h * 64 + (int)__builtin_ctzll(mm);
-					mm &= mm - 1ull;
-					const float4 r0 = s_rec[j * S_REC_F4 + 0];
-					const float4 r1 = s_rec[j * S_REC_F4 + 1];
-					const float4 r2 = s_rec[j * S_REC_F4 + 2];
-					const float4 r3 = s_rec[j * S_REC_F4 + 3];
-					SurfelPair o;
-					bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
-					float test_T = 0.f;
-					if (ok) {
-						test_T = T * (1 - o.alpha);
-						if (test_T < 0.0001f) {
-							done = true;
-							ok = false;
-						}
-					}
-					if (__ballot(ok) != 0ull) {
-						const float4 r4 = s_rec[j * S_REC_F4 + 4];
-						float w = 0.f;
-						if (ok) {
-							w = o.alpha * T;
-							const float A = 1 - T;
-							const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(o.depth));
-							distortion += (m * m * A + M2 - 2 * m * M1) * w;
-							Dp += o.depth * w;
-							M1 += m * w;
-							M2 += m * m * w;
-							if (T > 0.5f) {
-								median_depth = o.depth;
-								median_contributor = (float)(base + j + 1);
-							}
-							N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
-							C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
-							RS = fmaf(r4.z, w, RS);
-							if (r4.w != 0.f) mask = 1.0f;
-							T = test_T;
-							last_contributor = (uint32_t)(base + j + 1);
-						}
-						// gaussian_weights (forward.cu:458-459): max over the wave's pixels, merged per tile below
-						const float wm = wave_max_pos(w);
-						if (lane == 63) s_wmax[wave][j] = wm;
-					} else if (__ballot(!done) == 0ull) {
-						all_done = true;
-					}
+			float test_T = 0.f;
+			if (ok) {
+				test_T = T * (1 - o.alpha);
+				if (test_T < 0.0001f) {
+					done = true;
+					ok = false;
 				}
+			}
+			if (__ballot(ok) != 0ull) {
+				float w = 0.f;
+				if (ok) {
+					w = o.alpha * T;
+					const float A = 1 - T;
+					const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(o.depth));
+					distortion += (m * m * A + M2 - 2 * m * M1) * w;
+					Dp += o.depth * w;
+					M1 += m * w;
+					M2 += m * m * w;
+					if (T > 0.5f) {
+						median_depth = o.depth;
+						median_contributor = (float)contributor;
+					}
+					N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
+					C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
+					RS = fmaf(r4.z, w, RS);
+					if (r4.w != 0.f) mask = 1.0f;
+					T = test_T;
+					last_contributor = contributor;
+				}
+				// gaussian_weights (forward.cu:458-459): max over the wave's pixels; merged across waves by atomicMax
+				const float wm = wave_max_pos(w);
+				if (lane == 63) s_wmax[k] = wm;
+				touched |= 1ull << k;
+			} else if (__ballot(!done) == 0ull) {
+				break;
 			}
 		}
 		__syncthreads();
-		if (tid < nb) {
-			const float m = fmaxf(fmaxf(s_wmax[0][tid], s_wmax[1][tid]), fmaxf(s_wmax[2][tid], s_wmax[3][tid]));
-			// w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
-			// check-then-atomicExch is racy, this is the true maximum
-			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + s_id[tid], __float_as_int(m));
+		// ---- 3. w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
+		// check-then-atomicExch is racy, this is the true maximum
+		if (lane < nh && ((touched >> lane) & 1ull)) {
+			const float m = s_wmax[lane];
+			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + hid, __float_as_int(m));
 		}
+		__syncthreads();
 	}
 	if (inside) {
 		const size_t HW = (size_t)H * W;
@@ -446,7 +439,7 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
                                                 int contributor, float pixx, float pixy, float* v) {
 	const float alpha = o.alpha, G = o.G, c_d = o.depth;
 	const float Twx = r2.x, Twy = r2.y;
-	s.T = s.T / (1.f - alpha);
+	s.T = div_nr(s.T, 1.f - alpha);
 	const float T = s.T;
 	const float dchannel_dcolor = alpha * T;
 	const float last_alpha = s.last_alpha;
@@ -462,7 +455,7 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 	v[SA_REFL] = dchannel_dcolor * s.dr;
 	float dL_dz = 0.0f, dL_dweight = 0.f;
 	const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(c_d));
-	const float dmd_dd = (S_FAR * S_NEAR) / ((S_FAR - S_NEAR) * c_d * c_d);
+	const float dmd_dd = div_nr(S_FAR * S_NEAR, (S_FAR - S_NEAR) * c_d * c_d);
 	if (contributor == s.median_contributor - 1) dL_dz += s.dL_dmedian_depth;
 	dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2 * m_d * s.final_D) * s.dL_dreg;
 	dL_dalpha += dL_dweight - s.last_dL_dT;
@@ -481,13 +474,13 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 	v[SA_NORMAL + 2] = alpha * T * s.dnz;
 	dL_dalpha *= T;
 	s.last_alpha = alpha;
-	dL_dalpha += (-s.T_final / (1.f - alpha)) * s.bg_dot_dpixel;
+	dL_dalpha += div_nr(-s.T_final, 1.f - alpha) * s.bg_dot_dpixel;
 	const float dL_dG = r3.z * dL_dalpha;
 	dL_dz += alpha * T * s.dL_ddepth;
 	if (o.rho3d <= o.rho2d) {
 		const float dL_dsx = dL_dG * -G * o.sx + dL_dz * Twx;
 		const float dL_dsy = dL_dG * -G * o.sy + dL_dz * Twy;
-		const float dsx_pz = dL_dsx / o.pz, dsy_pz = dL_dsy / o.pz;
+		const float dsx_pz = div_nr(dL_dsx, o.pz), dsy_pz = div_nr(dL_dsy, o.pz);
 		const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * o.sx + dsy_pz * o.sy);
 		// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
 		const float dkx = o.ly * dpz - o.lz * dpy, dky = o.lz * dpx - o.lx * dpz, dkz = o.lx * dpy - o.ly * dpx;
@@ -519,7 +512,6 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 //   4. the wave flushes the parked rows as 80-byte contiguous float atomics into acc[P][20].
 // No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
 // threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
-#define S_WBATCH 64
 __device__ __forceinline__ void
 surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
@@ -851,9 +843,11 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	if (R < 0) return R;
 
 	const int nblocks = ((ntiles + 7) / 8) * 8;
-{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); 	surfel_render_fwd_kernel<<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
-	                                                      option_cull(), background,
-	                                                      img.final_T, img.n_contrib, out_color, out_others, out_refl_strength_map, gaussian_weights); }
+{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
+	const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+	                                                         option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
+	                                                         out_refl_strength_map, gaussian_weights); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
 }
