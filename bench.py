@@ -41,24 +41,19 @@ def yaw_camera(S, W, H, deg):
 
 class Scene:
     """Parameters of the synthetic scene as leaf tensors whose .grad are views into ONE flat buffer
-    (the all-reduce payload: 59 floats per Gaussian + cubemap texels + fail value)."""
+    (gsr_dist.FlatGrads: the all-reduce payload, 59 floats per Gaussian + cubemap texels + fail value)."""
 
     def __init__(self, S, P, mu, L, device, seed):
+        from gsr_dist import FlatGrads
         sc = S.make_scene(P, "S", seed=seed, mu=mu)
         tex, fail = S.make_cubemap(L, 3, seed)
         names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
         src = {k: torch.from_numpy(sc[k]) for k in names}
         src["cubemap"] = torch.from_numpy(tex)
         src["fail"] = torch.from_numpy(fail)
-        total = sum(v.numel() for v in src.values())
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.p = {}
-        off = 0
-        for k, v in src.items():
-            t = v.to(device).requires_grad_(True)
-            t.grad = self.flat_grad[off:off + v.numel()].view(v.shape)
-            off += v.numel()
-            self.p[k] = t
+        self.p = {k: v.to(device).requires_grad_(True) for k, v in src.items()}
+        self.grads = FlatGrads(self.p)
+        self.flat_grad = self.grads.flat
         self.mask = torch.from_numpy(sc["env_scope_mask"]).to(device)
         self.P = P
 
@@ -130,8 +125,7 @@ def main():
         means2D.grad = None
         final, allmap = forward()
         torch.autograd.backward([final, allmap], [g_final, g_allmap])
-        if dist_on:
-            dist.all_reduce(scene.flat_grad)
+        scene.grads.all_reduce()
 
     def sync_all():
         if dist_on:

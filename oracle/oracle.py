@@ -292,3 +292,23 @@ def cubemap_backward(grad_outputs, inputs, cubemap, interp=1, seamless=1, dtype=
     if B:
         getattr(lib(), f"orc_cubemap_backward_{_suf(dtype)}")(_p(g), _p(x), _p(cm), _p(gcm), _p(gin), _p(gf), int(interp), int(seamless), B, C, L)
     return gin, gcm, gf
+
+
+def sh_forward(deg, means, campos, shs, dtype=np.float32):
+    """computeColorFromSH forward (DSR/DGR forward.cu:20-71): returns (rgb [N,3] clamped at 0, clamped flags [N,3])."""
+    m, c, s = _arr(means, dtype), _arr(campos, dtype), _arr(shs, dtype)
+    N, M = m.shape[0], s.shape[1]
+    rgb = np.zeros((N, 3), dtype)
+    cl = np.zeros((N, 3), np.uint8)
+    getattr(lib(), f"orc_sh_forward_{_suf(dtype)}")(N, int(deg), M, _p(m), _p(c), _p(s), _p(rgb), _p(cl))
+    return rgb, cl
+
+
+def sh_backward(deg, means, campos, shs, clamped, dL_dcolor, dtype=np.float32):
+    m, c, s, g = _arr(means, dtype), _arr(campos, dtype), _arr(shs, dtype), _arr(dL_dcolor, dtype)
+    cl = np.ascontiguousarray(clamped, dtype=np.uint8)
+    N, M = m.shape[0], s.shape[1]
+    dm = np.zeros((N, 3), dtype)
+    ds = np.zeros((N, M, 3), dtype)
+    getattr(lib(), f"orc_sh_backward_{_suf(dtype)}")(N, int(deg), M, _p(m), _p(c), _p(s), _p(cl), _p(g), _p(dm), _p(ds))
+    return dm, ds

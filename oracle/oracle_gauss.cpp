@@ -532,3 +532,18 @@ using namespace orc;
 
 GAUSS_API(f32, float)
 GAUSS_API(f64, double)
+
+// Direct access to the shared SH restatement (pinned against the reference's utils/sh_utils.py golden vectors).
+#define SH_API(SUF, R)                                                                                                              \
+	extern "C" void orc_sh_forward_##SUF(int N, int deg, int M, const R* means, const R* campos, const R* shs, R* rgb, uint8_t* clamped) { \
+		for (int i = 0; i < N; i++) {                                                                                               \
+			V3<R> c = sh_forward<R>(i, deg, M, means, campos, shs, clamped);                                                        \
+			rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;                                                           \
+		}                                                                                                                           \
+	}                                                                                                                               \
+	extern "C" void orc_sh_backward_##SUF(int N, int deg, int M, const R* means, const R* campos, const R* shs, const uint8_t* clamped, \
+	                                      const R* dL_dcolor, R* dL_dmeans, R* dL_dshs) {                                           \
+		for (int i = 0; i < N; i++) sh_backward<R>(i, deg, M, means, campos, shs, clamped, dL_dcolor, dL_dmeans, dL_dshs);          \
+	}
+SH_API(f32, float)
+SH_API(f64, double)

@@ -1,0 +1,93 @@
+"""N > 1 path on the CPU: world_size-2 gloo process group.  Each rank differentiates its share of a batch of views
+(through the CPU oracle: test infrastructure standing in for the GPU rasterizer, which has no CPU fallback), the flat
+gradient buffer is all-reduced, and the result must equal the serial sum over all views."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _view_grads(view_idx, n_views, P, W, H):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    import gsr_synth as S
+    from oracle import oracle as orc
+    cams = S.circle_cameras(W, H, n=n_views)
+    sc = S.make_scene(P, "S", seed=1004, mu=-2.2, ball=True)
+    cam = cams[view_idx]
+    g = S.make_upstream_grads(H, W, 1004 + view_idx)
+    o = orc.SurfelOracle(np.float32)
+    o.forward(bg=np.zeros(3, np.float32), means3D=sc["means3D"], opacities=sc["opacities"], viewmatrix=cam["viewmatrix"],
+              projmatrix=cam["projmatrix"], campos=cam["campos"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=H,
+              image_width=W, sh_degree=3, shs=sc["shs"], refl_strengths=sc["refl_strengths"], scales=sc["scales"],
+              rotations=sc["rotations"], env_scope_mask=sc["env_scope_mask"])
+    gr = o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
+    return {"means3D": gr["dL_dmeans3D"], "shs": gr["dL_dsh"], "opacities": gr["dL_dopacity"], "scales": gr["dL_dscales"],
+            "rotations": gr["dL_drotations"], "refl_strengths": gr["dL_drefl_strengths"]}, \
+        (np.linalg.norm(gr["dL_dmeans2D"][:, :2], axis=1), (o.state("radii") > 0).astype(np.float32), o.state("radii").astype(np.float32))
+
+
+def _worker(rank, world, port, n_views, P, W, H, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_dist import FlatGrads, reduce_densification_stats, shard_views
+    shapes = {"means3D": (P, 3), "shs": (P, 16, 3), "opacities": (P, 1), "scales": (P, 2), "rotations": (P, 4), "refl_strengths": (P, 1)}
+    params = {k: torch.zeros(s, requires_grad=True) for k, s in shapes.items()}
+    fg = FlatGrads(params)
+    assert fg.flat.numel() == P * 59
+    fg.zero_()
+    gn, vis, rad = torch.zeros(P), torch.zeros(P), torch.zeros(P)
+    for v in shard_views(n_views, rank, world):
+        grads, (g2, visible, radii) = _view_grads(v, n_views, P, W, H)
+        for k in params:
+            params[k].grad += torch.from_numpy(grads[k]).reshape(shapes[k])   # what autograd's AccumulateGrad does in place
+        gn += torch.from_numpy(g2)
+        vis += torch.from_numpy(visible)
+        rad = torch.maximum(rad, torch.from_numpy(radii))
+    fg.all_reduce()
+    reduce_densification_stats(gn, vis, rad)
+    if rank == 0:
+        torch.save({"flat": fg.flat.clone(), "gn": gn, "vis": vis, "rad": rad}, os.path.join(out_dir, "reduced.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_views_partition():
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_dist import shard_views
+    for world in (1, 2, 4, 8, 3):
+        got = sorted(v for r in range(world) for v in shard_views(8, r, world))
+        assert got == list(range(8))
+        sizes = [len(shard_views(8, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gradient_allreduce_matches_serial(tmp_path):
+    n_views, P, W, H = 4, 1500, 96, 64
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, n_views, P, W, H, str(tmp_path)), nprocs=2, join=True)
+    red = torch.load(os.path.join(str(tmp_path), "reduced.pt"), weights_only=True)
+    # serial reference: sum over all views in one process
+    order = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
+    tot = None
+    gn, vis, rad = np.zeros(P, np.float32), np.zeros(P, np.float32), np.zeros(P, np.float32)
+    for v in range(n_views):
+        grads, (g2, visible, radii) = _view_grads(v, n_views, P, W, H)
+        flat = np.concatenate([grads[k].reshape(-1) for k in order])
+        tot = flat if tot is None else tot + flat
+        gn += g2
+        vis += visible
+        rad = np.maximum(rad, radii)
+    np.testing.assert_allclose(red["flat"].numpy(), tot, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(red["gn"].numpy(), gn, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(red["vis"].numpy(), vis)
+    np.testing.assert_array_equal(red["rad"].numpy(), rad)
+    assert np.abs(tot).max() > 0 and vis.max() == n_views
