@@ -191,101 +191,93 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 	return !(alpha < 1.0f / 255.0f);
 }
 
-// renderCUDA forward (DGR forward.cu:274-411)
+// renderCUDA forward (DGR forward.cu:274-411), wave-per-quadrant form (see surfel_render_fwd_wave_kernel in
+// gsr_surfel.hip for the design: one wave = one 8x8 pixel block, ballot-compacted private work list from
+// conservative cull bounds, per-Gaussian record through the scalar memory path, no workgroup barriers).
+#define G_WBATCH 64
 template <bool INVDEPTH>
-__global__ void __launch_bounds__(256)
-gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                        const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
-                        float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                        float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
-	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-	if (tile >= (uint32_t)ntiles) return;
+__global__ void __launch_bounds__(64)
+gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                             const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
+                             float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                             float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);
+	if (unit >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const int lane = threadIdx.x;
+	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
+	if (bx0 >= W || by0 >= H) return;
+	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixx = (float)px, pixy = (float)py;
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
+	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float4 s_rec[256 * G_REC_F4];
-	__shared__ float4 s_bbox[256];
-	__shared__ int s_done[4];
-	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
-	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
+	__shared__ uint32_t s_hid[G_WBATCH];
+	__shared__ uint32_t s_hj[G_WBATCH];
 
 	bool done = !inside;
 	float T = 1.0f;
 	uint32_t last_contributor = 0;
 	float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, RS = 0, ID = 0;
 
-	for (int base = 0; base < count; base += 256) {
-		// block-wide "everyone done" vote (reference: __syncthreads_count(done) == BLOCK_SIZE)
-		const bool wave_done = __ballot(!done) == 0ull;
-		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
-		__syncthreads();
-		if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == 4) break;
-		// cooperative gather: 4 lanes per 64-byte record
-		const int nb = min(256, count - base);
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const int i = k * 64 + (tid >> 2);
-			if (i < nb) {
-				const uint32_t id = point_list[range.x + base + i];
-				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
+	for (int base = 0; base < count; base += G_WBATCH) {
+		if (__ballot(!done) == 0ull) break;
+		const int nb = min(G_WBATCH, count - base);
+		bool hit = lane < nb;
+		uint32_t id = 0;
+		if (hit) {
+			id = point_list[range.x + (uint32_t)(base + lane)];
+			if (cull) {
+				const float4 bb = bbox[id];
+				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 			}
 		}
-		if (tid < nb) s_bbox[tid] = bbox[point_list[range.x + base + tid]];
+		const unsigned long long mm = __ballot(hit);
+		const int nh = __popcll(mm);
+		if (nh == 0) continue;
+		if (hit) {
+			const int k = __popcll(mm & ((1ull << lane) - 1ull));
+			s_hid[k] = id;
+			s_hj[k] = (uint32_t)lane;
+		}
 		__syncthreads();
-		if (!wave_done) {
-			// per-wave key compaction (see surfel_render_fwd_kernel)
-			unsigned long long hits[4];
-#pragma unroll
-			for (int h = 0; h < 4; h++) {
-				const int e = h * 64 + lane;
-				bool hit = e < nb;
-				if (hit && cull) {
-					const float4 bb = s_bbox[e];
-					hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
-				}
-				hits[h] = __ballot(hit);
+		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
+		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
+		__syncthreads();
+		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * G_REC_F4;
+		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3];
+		for (int k = 0; k < nh; k++) {
+			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
+			float dx, dy, G, alpha;
+			bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+			if (k + 1 < nh) {
+				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
+				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
 			}
-			bool all_done = false;
-#pragma unroll
-			for (int h = 0; h < 4; h++) {
-				unsigned long long mm = hits[h];
-				while (mm != 0ull && !all_done) {
-					const int j = h * 64 + (int)__builtin_ctzll(mm);
-					mm &= mm - 1ull;
-					const float4 r0 = s_rec[j * G_REC_F4 + 0];
-					const float4 r1 = s_rec[j * G_REC_F4 + 1];
-					float dx, dy, G, alpha;
-					bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
-					float test_T = 0.f;
-					if (ok) {
-						test_T = T * (1 - alpha);
-						if (test_T < 0.0001f) {
-							done = true;
-							ok = false;
-						}
-					}
-					if (__ballot(ok) != 0ull) {
-						const float4 r2 = s_rec[j * G_REC_F4 + 2];
-						const float4 r3 = s_rec[j * G_REC_F4 + 3];
-						if (ok) {
-							const float w = alpha * T;
-							C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
-							N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
-							RS = fmaf(r3.x, w, RS);
-							if (INVDEPTH) ID = fmaf(r3.y, w, ID);
-							T = test_T;
-							last_contributor = (uint32_t)(base + j + 1);
-						}
-					} else if (__ballot(!done) == 0ull) {
-						all_done = true;
-					}
+			float test_T = 0.f;
+			if (ok) {
+				test_T = T * (1 - alpha);
+				if (test_T < 0.0001f) {
+					done = true;
+					ok = false;
 				}
+			}
+			if (__ballot(ok) != 0ull) {
+				if (ok) {
+					const float w = alpha * T;
+					C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
+					N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
+					RS = fmaf(r3.x, w, RS);
+					if (INVDEPTH) ID = fmaf(r3.y, w, ID);
+					T = test_T;
+					last_contributor = contributor;
+				}
+			} else if (__ballot(!done) == 0ull) {
+				break;
 			}
 		}
 	}
@@ -305,38 +297,36 @@ gauss_render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 	}
 }
 
-// renderCUDA backward (DGR backward.cu:452-690).  The reference issues 16 float atomicAdds per
-// contributing (pixel, Gaussian) pair; here each wave reduces its 64 pixels with DPP adds, the four
-// waves meet in LDS, and one 64-byte row per (tile, Gaussian) goes out as four 16-byte-per-lane atomic
-// segments into a private [P][16] accumulator that the per-Gaussian kernel then consumes.
-#define G_BWD_BATCH 64
+// renderCUDA backward (DGR backward.cu:452-690), wave-per-quadrant form.  The reference issues 16 float
+// atomicAdds per contributing (pixel, Gaussian) pair; here the wave folds the 16 values with
+// v_permlane32/16_swap (4 values per register), finishes with four fused DPP row steps, parks the totals in LDS
+// and flushes one 64-byte row of atomics per touched Gaussian into acc[P][16].
 template <bool INVDEPTH>
-__global__ void __launch_bounds__(256)
-gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                        const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
-                        const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                        const float* __restrict__ dL_dnormal_map, const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_invdepths,
-                        float* __restrict__ acc) {
-	const uint32_t tile = xcd_tile(blockIdx.x, ntiles);
-	if (tile >= (uint32_t)ntiles) return;
+__global__ void __launch_bounds__(64)
+gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                             const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
+                             const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                             const float* __restrict__ dL_dnormal_map, const float* __restrict__ dL_drefl_map,
+                             const float* __restrict__ dL_invdepths, float* __restrict__ acc) {
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);
+	if (unit >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int px = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int py = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+	const int lane = threadIdx.x;
+	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
+	if (bx0 >= W || by0 >= H) return;
+	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixx = (float)px, pixy = (float)py;
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
 	const size_t HW = (size_t)H * W;
 	const size_t pix = (size_t)W * py + px;
+	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float4 s_rec[G_BWD_BATCH * G_REC_F4];
-	__shared__ float4 s_bbox[G_BWD_BATCH];
-	__shared__ uint32_t s_id[G_BWD_BATCH];
-	const float qx0 = (float)(tile_x * 16 + (wave & 1) * 8), qy0 = (float)(tile_y * 16 + (wave >> 1) * 8);
-	const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
-	__shared__ float4 s_slab[4][G_BWD_BATCH][G_ACC_F / 4];
-	__shared__ unsigned long long s_touched[4];
+	__shared__ float s_slab[G_WBATCH * G_ACC_F];
+	__shared__ uint32_t s_hid[G_WBATCH];
+	__shared__ uint32_t s_hj[G_WBATCH];
 
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
@@ -353,47 +343,51 @@ gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 	const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
 
-	for (int base = 0; base < count; base += G_BWD_BATCH) {
-		const int nb = min(G_BWD_BATCH, count - base);
-		__syncthreads();  // previous batch fully flushed before its LDS is overwritten
-		{
-			const int i = tid >> 2;
-			if (i < nb) {
-				const uint32_t id = point_list[range.y - 1 - (uint32_t)(base + i)];
-				s_rec[i * G_REC_F4 + (tid & 3)] = rec[(size_t)id * G_REC_F4 + (tid & 3)];
-				if ((tid & 3) == 0) {
-					s_id[i] = id;
-					s_bbox[i] = bbox[id];
-				}
-			}
-		}
-		__syncthreads();
-		unsigned long long touched = 0ull;
-		unsigned long long mm;
-		{
-			bool hit = lane < nb;
-			if (hit && cull) {
-				const float4 bb = s_bbox[lane];
+	int wave_last = last_contributor;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+	if (wave_last == 0) return;
+	const int first = max(0, count - wave_last);
+	for (int base = (first / G_WBATCH) * G_WBATCH; base < count; base += G_WBATCH) {
+		const int nb = min(G_WBATCH, count - base);
+		bool hit = lane < nb && (count - 1 - (base + lane)) < wave_last;
+		uint32_t id = 0;
+		if (hit) {
+			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
+			if (cull) {
+				const float4 bb = bbox[id];
 				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
 			}
-			mm = __ballot(hit);
 		}
-		while (mm != 0ull) {
-			const int j = (int)__builtin_ctzll(mm);
-			mm &= mm - 1ull;
-			const int contributor = count - 1 - (base + j);  // index in the front-to-back list
-			const float4 r0 = s_rec[j * G_REC_F4 + 0];
-			const float4 r1 = s_rec[j * G_REC_F4 + 1];
+		const unsigned long long mm = __ballot(hit);
+		const int nh = __popcll(mm);
+		if (nh == 0) continue;
+		if (hit) {
+			const int k = __popcll(mm & ((1ull << lane) - 1ull));
+			s_hid[k] = id;
+			s_hj[k] = (uint32_t)lane;
+		}
+		__syncthreads();
+		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
+		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
+		unsigned long long touched = 0ull;
+		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * G_REC_F4;
+		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3];
+		for (int k = 0; k < nh; k++) {
+			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			float dx, dy, G, alpha;
 			const bool ok = inside && contributor < last_contributor && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+			if (k + 1 < nh) {
+				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
+				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+			}
 			if (__ballot(ok) == 0ull) continue;
-			const float4 r2 = s_rec[j * G_REC_F4 + 2];
-			const float4 r3 = s_rec[j * G_REC_F4 + 3];
 			float v[G_ACC_F];
 #pragma unroll
 			for (int q = 0; q < G_ACC_F; q++) v[q] = 0.f;
 			if (ok) {
-				T = T / (1.f - alpha);
+				T = div_nr(T, 1.f - alpha);
 				const float dchannel_dcolor = alpha * T;
 				float dL_dalpha = 0.0f, dL_dalpha_means2d = 0.0f;
 				// colour channels; dL_dalpha_means2d is the running sum INSIDE the loop (DGR backward.cu:613-614)
@@ -423,7 +417,7 @@ gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 				dL_dalpha *= T;
 				dL_dalpha_means2d *= T;
 				last_alpha = alpha;
-				const float bgterm = (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+				const float bgterm = div_nr(-T_final, 1.f - alpha) * bg_dot_dpixel;
 				dL_dalpha += bgterm;
 				dL_dalpha_means2d += bgterm;
 				const float dL_dG = r1.y * dL_dalpha;
@@ -440,40 +434,25 @@ gauss_render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __rest
 				v[GA_CONIC + 2] = -0.5f * gdy * dy * dL_dG;
 				v[GA_OPAC] = G * dL_dalpha;
 			}
-			wave_sum8(v);
-			wave_sum8(v + 8);
-			if (lane == 63) {
-				s_slab[wave][j][0] = make_float4(v[0], v[1], v[2], v[3]);
-				s_slab[wave][j][1] = make_float4(v[4], v[5], v[6], v[7]);
-				s_slab[wave][j][2] = make_float4(v[8], v[9], v[10], v[11]);
-				s_slab[wave][j][3] = make_float4(v[12], v[13], v[14], v[15]);
-			}
-			touched |= 1ull << j;
-		}
-		if (lane == 0) s_touched[wave] = touched;
-		__syncthreads();
-		{
-			const int i = tid >> 2, q = tid & 3;
-			if (i < nb) {
-				float4 s = make_float4(0, 0, 0, 0);
-				bool any = false;
+			float z[4];
 #pragma unroll
-				for (int w = 0; w < 4; w++) {
-					if ((s_touched[w] >> i) & 1ull) {
-						const float4 t = s_slab[w][i][q];
-						s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-						any = true;
-					}
-				}
-				if (any) {
-					float* dst = acc + (size_t)s_id[i] * G_ACC_F + q * 4;
-					atomicAdd(dst + 0, s.x);
-					atomicAdd(dst + 1, s.y);
-					atomicAdd(dst + 2, s.z);
-					atomicAdd(dst + 3, s.w);
-				}
+			for (int g = 0; g < 4; g++) z[g] = fold4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+			row_sum4(z);
+			if ((lane & 15) == 15) {
+				float* slab = s_slab + k * G_ACC_F + fold_slot(lane);
+#pragma unroll
+				for (int g = 0; g < 4; g++) slab[4 * g] = z[g];
+			}
+			touched |= 1ull << k;
+		}
+		__syncthreads();
+		if (touched != 0ull) {
+			for (int item = lane; item < nh * G_ACC_F; item += 64) {
+				const int k = item / G_ACC_F, d = item - k * G_ACC_F;
+				if ((touched >> k) & 1ull) atomicAdd(acc + (size_t)s_hid[k] * G_ACC_F + d, s_slab[item]);
 			}
 		}
+		__syncthreads();
 	}
 }
 
@@ -709,17 +688,18 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
 	if (R < 0) return R;
 
-	const int nblocks = ((ntiles + 7) / 8) * 8;
-	if (out_invdepth)
-		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
-		                                                          option_cull(), background,
-		                                                          img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
-		                                                          out_invdepth); }
-	else
-		{ StageTimer st_(GSR_STAGE_RENDER_FWD, stream); gauss_render_fwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
-		                                                          option_cull(), background,
-		                                                           img.final_T, img.n_contrib, out_color, out_normal_map, out_refl_strength_map,
-		                                                           nullptr); }
+	const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+	{
+		StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
+		if (out_invdepth)
+			gauss_render_fwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+			                                                              option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
+			                                                              out_refl_strength_map, out_invdepth);
+		else
+			gauss_render_fwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+			                                                               option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
+			                                                               out_refl_strength_map, nullptr);
+	}
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
 }
@@ -752,17 +732,18 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * G_ACC_F * sizeof(float), stream));
 	if (R > 0) {
-		const int nblocks = ((ntiles + 7) / 8) * 8;
-		if (dL_invdepths)
-			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<true><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-			                                                          geom.bbox, option_cull(),
-			                                                          img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
-			                                                          dL_invdepths, geom.acc); }
-		else
-			{ StageTimer st_(GSR_STAGE_RENDER_BWD, stream); gauss_render_bwd_kernel<false><<<nblocks, 256, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-			                                                          geom.bbox, option_cull(),
-			                                                           img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map, dL_drefl_strength_map,
-			                                                           nullptr, geom.acc); }
+		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+		{
+			StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
+			if (dL_invdepths)
+				gauss_render_bwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+				                                                              geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
+				                                                              dL_drefl_strength_map, dL_invdepths, geom.acc);
+			else
+				gauss_render_bwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+				                                                               geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
+				                                                               dL_drefl_strength_map, nullptr, geom.acc);
+		}
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
