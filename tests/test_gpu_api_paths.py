@@ -1,0 +1,182 @@
+"""GPU parity for the less-travelled API paths and the reference's edge cases: precomputed colours, precomputed
+transMat / cov3D, SH degrees and coefficient counts, scale_modifier (incl. the surfel backward ignoring it), P = 0,
+markVisible, the prefiltered trap, debug mode, the multi-view ball scene of config C4, maximum-size keys."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import HipGauss, HipSurfel, S, psnr, rel_maxnorm, scene_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def _orc():
+    from oracle import oracle as orc
+    return orc
+
+
+def _cmp_surfel(kw, grads=("dL_dmeans3D", "dL_dopacity", "dL_drefl_strengths"), scale_modifier=1.0, tol=1e-4):
+    orc = _orc()
+    H, W = kw["image_height"], kw["image_width"]
+    o = orc.SurfelOracle(np.float32)
+    ref = o.forward(scale_modifier=scale_modifier, **kw)
+    hip = HipSurfel(kw, scale_modifier=scale_modifier)
+    out = hip.out()
+    assert out["num_rendered"] == ref["num_rendered"]
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    assert psnr(out["color"], ref["color"]) >= 50 and psnr(out["allmap"], ref["allmap"], peak=max(1.0, float(np.abs(ref["allmap"]).max()))) >= 50
+    g = S.make_upstream_grads(H, W, 3)
+    gr = o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
+    gh = hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    for k in grads:
+        assert gh[k] is not None, k
+        assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= tol, k
+    return ref, out, gr, gh
+
+
+def _cmp_gauss(kw, grads=("dL_dmeans3D", "dL_dopacity", "dL_dnormals", "dL_drefl_strengths"), aa=False, scale_modifier=1.0):
+    orc = _orc()
+    H, W = kw["image_height"], kw["image_width"]
+    o = orc.GaussOracle(np.float32)
+    ref = o.forward(antialiasing=aa, scale_modifier=scale_modifier, **kw)
+    hip = HipGauss(kw, antialiasing=aa, scale_modifier=scale_modifier)
+    out = hip.out()
+    assert out["num_rendered"] == ref["num_rendered"]
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    for k in ("color", "normal_map", "invdepth", "refl_strength_map"):
+        assert psnr(out[k], ref[k], peak=max(1.0, float(np.abs(ref[k]).max()))) >= 50, k
+    g = S.make_upstream_grads(H, W, 3)
+    gr = o.backward(dL_dcolor=g["dL_dcolor"], dL_dinvdepth=g["dL_dinvdepth"], dL_dnormal_map=g["dL_dnormal"], dL_drefl_strength_map=g["dL_drefl"])
+    gh = hip.backward(g["dL_dcolor"], g["dL_dinvdepth"], g["dL_dnormal"], g["dL_drefl"])
+    for k in grads:
+        assert gh[k] is not None, k
+        assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
+    return ref, out, gr, gh
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_sh_degrees_surfel_and_gauss(deg):
+    kw, _, _ = scene_kwargs("S", 3000, 160, 120, 40 + deg, -2.8, deg, (0.1, 0.1, 0.1))
+    _cmp_surfel(kw, grads=("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"))
+    kw, _, _ = scene_kwargs("G", 3000, 160, 120, 50 + deg, -2.8, deg, (0.1, 0.1, 0.1))
+    ref, out, gr, gh = _cmp_gauss(kw, grads=("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"))
+    ncoef = (deg + 1) ** 2
+    assert np.abs(gh["dL_dsh"][:, ncoef:, :]).max() == 0   # coefficients above the active degree get exact zeros
+
+
+def test_sh_with_four_coefficients_only():
+    """M = 4 (degree-1 tensor): rows are 48 bytes, exercises the non-192-byte row path."""
+    kw, _, _ = scene_kwargs("G", 2000, 128, 96, 61, -2.8, 1, (0, 0, 0))
+    kw["shs"] = np.ascontiguousarray(kw["shs"][:, :4, :])
+    _cmp_gauss(kw, grads=("dL_dsh", "dL_dmeans3D"))
+    kw, _, _ = scene_kwargs("S", 2000, 128, 96, 62, -2.8, 0, (0, 0, 0))
+    kw["shs"] = np.ascontiguousarray(kw["shs"][:, :1, :])    # M = 1: 12-byte rows, scalar-load fallback
+    _cmp_surfel(kw, grads=("dL_dsh", "dL_dmeans3D"))
+
+
+def test_precomputed_colors():
+    rs = np.random.RandomState(5)
+    kw, _, _ = scene_kwargs("S", 3000, 160, 120, 70, -2.8, 3, (1, 1, 1))
+    kw["colors_precomp"] = rs.rand(3000, 3).astype(np.float32)
+    kw["shs"] = None
+    ref, out, gr, gh = _cmp_surfel(kw, grads=("dL_dmeans3D", "dL_dcolors", "dL_dopacity"))
+    kw, _, _ = scene_kwargs("G", 3000, 160, 120, 71, -2.8, 3, (1, 1, 1))
+    kw["colors_precomp"] = rs.rand(3000, 3).astype(np.float32)
+    kw["shs"] = None
+    _cmp_gauss(kw, grads=("dL_dmeans3D", "dL_dcolors", "dL_dopacity"))
+
+
+def test_surfel_precomputed_transmat():
+    """pipe.compute_cov3D_python path: the caller supplies T (P,9) and gets dL_dtransMat back (DSR backward.cu:499-575)."""
+    orc = _orc()
+    kw, _, _ = scene_kwargs("S", 3000, 160, 120, 80, -2.8, 3, (0, 0, 0))
+    o = orc.SurfelOracle(np.float32)
+    o.forward(**kw)
+    T = o.state("transMat")
+    vis = o.state("radii") > 0
+    T[~vis] = np.eye(3, dtype=np.float32).reshape(-1)     # culled Gaussians never wrote their T
+    kw2 = dict(kw)
+    kw2["cov3D_precomp"] = T
+    kw2["scales"] = None
+    kw2["rotations"] = None
+    _cmp_surfel(kw2, grads=("dL_dtransMat", "dL_dmeans3D", "dL_dopacity"))
+
+
+def test_gauss_precomputed_cov3d():
+    orc = _orc()
+    kw, _, _ = scene_kwargs("G", 3000, 160, 120, 81, -2.8, 3, (0, 0, 0))
+    o = orc.GaussOracle(np.float32)
+    o.forward(**kw)
+    cov = o.state("cov3D")
+    vis = o.state("radii") > 0
+    cov[~vis] = np.array([1e-2, 0, 0, 1e-2, 0, 1e-2], np.float32)
+    kw2 = dict(kw)
+    kw2["cov3D_precomp"] = cov
+    kw2["scales"] = None
+    kw2["rotations"] = None
+    _cmp_gauss(kw2, grads=("dL_dcov3D", "dL_dmeans3D"), aa=True)
+
+
+def test_scale_modifier():
+    """Forward honours scale_modifier; the surfel backward rebuilds T with modifier 1 (DSR backward.cu:511) and the
+    oracle reproduces that, so parity must hold for modifier != 1 as well."""
+    kw, _, _ = scene_kwargs("S", 3000, 160, 120, 90, -3.0, 3, (0, 0, 0))
+    _cmp_surfel(kw, grads=("dL_dmeans3D", "dL_dscales", "dL_drotations"), scale_modifier=1.7)
+    kw, _, _ = scene_kwargs("G", 3000, 160, 120, 91, -3.0, 3, (0, 0, 0))
+    _cmp_gauss(kw, grads=("dL_dmeans3D", "dL_dscales", "dL_drotations"), scale_modifier=0.6)
+
+
+def test_c4_ball_scene_circle_cameras():
+    """Config C4 geometry: Gaussians in a ball around the origin seen from cameras on a circle (non-identity view matrix)."""
+    cams = S.circle_cameras(200, 150, n=8)
+    for v in (1, 6):
+        kw, _, _ = scene_kwargs("S", 6000, 200, 150, 1004, -2.6, 3, (0, 0, 0), cam=cams[v], ball=True)
+        _cmp_surfel(kw, grads=("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dopacity"))
+    kw, _, _ = scene_kwargs("G", 6000, 200, 150, 1004, -2.6, 3, (0, 0, 0), cam=cams[3], ball=True)
+    _cmp_gauss(kw, grads=("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dopacity"), aa=True)
+
+
+def test_empty_and_tiny_inputs():
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cam = S.make_camera(64, 48)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    st = GaussianRasterizationSettings(image_height=48, image_width=64, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                       bg=torch.tensor([0.2, 0.3, 0.4]).cuda(), scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]),
+                                       projmatrix=t(cam["projmatrix"]), sh_degree=0, campos=t(cam["campos"]), prefiltered=False, debug=False)
+    r = GaussianRasterizer(st)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    # P = 0: zero outputs, num_rendered 0 (DSR rasterize_points.cu:111)
+    color, radii, allmap, refl, gw = r(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), shs=z(0, 16, 3), refl_strengths=z(0, 1),
+                                       scales=z(0, 2), rotations=z(0, 4), env_scope_mask=torch.zeros(0, dtype=torch.bool, device="cuda"))
+    assert color.shape == (3, 48, 64) and float(color.abs().max()) == 0 and radii.numel() == 0 and float(allmap.abs().max()) == 0
+    # everything culled (behind the near plane): image = background, no instances
+    m = z(5, 3)
+    color, radii, allmap, refl, gw = r(means3D=m, means2D=z(5, 3), opacities=z(5, 1) + 0.5, shs=z(5, 16, 3), refl_strengths=z(5, 1),
+                                       scales=z(5, 2) + 0.1, rotations=torch.tensor([[1.0, 0, 0, 0]] * 5).cuda(),
+                                       env_scope_mask=torch.ones(5, dtype=torch.bool, device="cuda"))
+    assert int(radii.max()) == 0
+    np.testing.assert_allclose(color[:, 10, 10].cpu().numpy(), [0.2, 0.3, 0.4], atol=1e-7)
+    assert list(r.markVisible(torch.tensor([[0, 0, 1.0], [0, 0, 0.1], [0, 0, 0.2]]).cuda()).cpu().numpy()) == [True, False, False]
+
+
+def test_prefiltered_trap_and_debug_mode():
+    import _gsr
+    kw, _, _ = scene_kwargs("S", 500, 64, 48, 7, -2.5, 0, (0, 0, 0))
+    with pytest.raises(_gsr.GsrError, match="filtered although prefiltered"):
+        HipSurfel(kw, prefiltered=True)          # the scene contains near-plane points: the reference would __trap()
+    hip = HipSurfel(kw, debug=True)              # debug: synchronise + check after every stage
+    assert hip.R > 0
+
+
+def test_max_tile_id_bits_and_large_splats():
+    """A few very large splats cover every tile (keys use all getHigherMsb(tiles) bits); checks the sort bit range."""
+    orc = _orc()
+    kw, _, _ = scene_kwargs("G", 300, 1920, 1080, 9, -1.0, 0, (0, 0, 0))
+    o = orc.GaussOracle(np.float32)
+    ref = o.forward(**kw)
+    hip = HipGauss(kw)
+    assert hip.R == ref["num_rendered"]
+    np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
+    np.testing.assert_array_equal(hip.state("ranges").astype(np.uint32), o.state("ranges"))
+    assert int(o.state("keys").max() >> np.uint64(32)) == 120 * 68 - 1
+    assert psnr(hip.out()["color"], ref["color"]) >= 50
