@@ -219,6 +219,18 @@ __device__ __forceinline__ float wave_max_pos(float v) {  // max over lanes of n
 }
 
 
+
+// exp(x) for x in [-88, 0]: exp2 of a two-float product x*log2(e) (hi from the multiply, lo from the FMA residual
+// plus the low word of log2(e)) with a first-order correction for lo.  ~1.5 ulp, 5 instructions; the plain
+// exp2(x*log2e) form loses |x| * 2^-24 relative (3e-7 at x = -5.5), which the ill-conditioned surfel backward
+// amplifies ~200x, and the ocml expf() costs ~3x more.
+__device__ __forceinline__ float exp_neg(float x) {
+	const float hi = x * 1.44269504f;
+	const float lo = fmaf(x, 1.44269504f, -hi) + x * 1.92596299e-8f;
+	const float e = __builtin_amdgcn_exp2f(hi);
+	return fmaf(e, 0.693147181f * lo, e);
+}
+
 // a / b with one Newton-Raphson correction on v_rcp_f32: correctly rounded except in rare last-bit cases,
 // ~8 ns per wave instead of ~18 ns for the IEEE v_div_scale/v_div_fmas/v_div_fixup sequence (measured,
 // tests/microbench/valu_rate.hip).  Only for operands known to be finite, normal and far from overflow

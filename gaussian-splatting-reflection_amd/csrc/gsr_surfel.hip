@@ -246,7 +246,7 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	if (o.depth < S_NEAR) return false;
 	const float power = -0.5f * rho;
 	if (power > 0.0f) return false;
-	o.G = expf(power);  // precise exp: the ~3e-7 argument-scaling error of exp2(x*log2e) is amplified ~200x by the ill-conditioned backward
+	o.G = exp_neg(power);  // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by the backward
 	o.alpha = fminf(0.99f, opac * o.G);
 	return !(o.alpha < 1.0f / 255.0f);
 }

@@ -62,16 +62,29 @@ def get_refl_color(envmap, HWK, R, T, normal_map):  # RT W2C
     return sample_cubemap_color(rays_d, envmap)
 
 
+_cam_cache = {}
+
+
 def _cam_block(world_view_transform, HWK, R, T):
-    """Packs the 33 camera floats gsr_deferred_reflection_* expects (see csrc/gsr_cubemap.hip)."""
+    """Packs the 33 camera floats gsr_deferred_reflection_* expects (see csrc/gsr_cubemap.hip).  Cached per camera
+    (keyed on the tensors' storage and version counters) so that a training loop does not rebuild it every step."""
+    key = (world_view_transform.data_ptr(), world_view_transform._version, R.data_ptr(), R._version, T.data_ptr(), T._version,
+           int(HWK[0]), int(HWK[1]), np.asarray(HWK[2], dtype=np.float32).tobytes())
+    hit = _cam_cache.get(key)
+    if hit is not None:
+        return hit
     dev = world_view_transform.device
     K = np.asarray(HWK[2]).astype(np.float32)
     Kinv = torch.tensor(np.linalg.inv(K), dtype=torch.float32, device=dev)
     Rw = R.T.contiguous().float()
-    T = T.float()
-    rays_o = (-Rw.T @ T.unsqueeze(-1)).flatten()
-    return torch.cat([world_view_transform[:3, :3].contiguous().float().reshape(-1), Kinv.reshape(-1), Rw.reshape(-1), T.reshape(-1),
-                      rays_o.reshape(-1)]).contiguous()
+    Tf = T.float()
+    rays_o = (-Rw.T @ Tf.unsqueeze(-1)).flatten()
+    cam = torch.cat([world_view_transform[:3, :3].contiguous().float().reshape(-1), Kinv.reshape(-1), Rw.reshape(-1), Tf.reshape(-1),
+                     rays_o.reshape(-1)]).contiguous()
+    if len(_cam_cache) > 256:
+        _cam_cache.clear()
+    _cam_cache[key] = cam
+    return cam
 
 
 class _DeferredReflection(torch.autograd.Function):
