@@ -573,22 +573,26 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
 		// current one is being differentiated.
 		unsigned long long touched = 0ull;
-		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * S_REC_F4;
-		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3], n4 = rp[4];
-		for (int k = 0; k < nh; k++) {
-			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4;
+		// Ping-pong between two SGPR record buffers (A, B): the s_load of the next record is issued right after the
+		// ray-splat evaluation of the current one and is only waited for one full gradient section later.  (With a
+		// single rotating buffer the compiler copies the loaded SGPRs and waits for the load immediately.)
+		struct Rec { float4 r0, r1, r2, r3, r4; };
+		auto fetch = [&](int k) -> Rec {
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
+			return Rec{q[0], q[1], q[2], q[3], q[4]};
+		};
+		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
 			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			SurfelPair o;
-			const bool ok = inside && contributor < st.last_contributor && surfel_pair<false>(r0, r1, r2, r3.z, pixx, pixy, o);
-			if (k + 1 < nh) {
-				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * S_REC_F4;
-				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-			}
-			if (__ballot(ok) == 0ull) continue;
+			const bool ok = inside && contributor < st.last_contributor && surfel_pair<false>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			__builtin_amdgcn_sched_barrier(0);
+			prefetch_next();
+			__builtin_amdgcn_sched_barrier(0);
+			if (__ballot(ok) == 0ull) return;
 			float v[S_ACC_F];
 #pragma unroll
 			for (int q = 0; q < S_ACC_F; q++) v[q] = 0.f;
-			if (ok) surfel_bwd_pair(st, o, r2, r3, r4, contributor, pixx, pixy, v);
+			if (ok) surfel_bwd_pair(st, o, R.r2, R.r3, R.r4, contributor, pixx, pixy, v);
 			// 20 values -> 5 registers of 4 folded values -> row sums; lanes 15/31/47/63 park one value each
 			float z[5];
 #pragma unroll
@@ -600,6 +604,12 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
 			}
 			touched |= 1ull << k;
+		};
+		Rec A = fetch(0), B = A;
+		for (int k = 0; k < nh; k += 2) {
+			differentiate(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); });
+			if (k + 1 >= nh) break;
+			differentiate(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); });
 		}
 		__syncthreads();
 		// ---- 4. flush: lane -> (hit k, float d); 80 contiguous bytes per surfel
