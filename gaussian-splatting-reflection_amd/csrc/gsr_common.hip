@@ -94,7 +94,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.point_offsets = c.take<uint32_t>(P);
 	g.clamped = c.take<uint8_t>(P);
 	g.rec = c.take<float4>(P * rec_f4);
-	g.bbox = c.take<float4>(P);
+	g.bbox = c.take<float4>(2 * P);
 	g.aux = c.take<float>(P * aux_floats);
 	g.acc = c.take<float>(P * acc_floats);
 	g.flags = c.take<int>(4);

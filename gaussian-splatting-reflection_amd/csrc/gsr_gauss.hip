@@ -159,18 +159,16 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	rec[2] = make_float4(cb, normals[3 * idx], normals[3 * idx + 1], normals[3 * idx + 2]);
 	rec[3] = make_float4(refl[idx], 1.0f / pvz, 0.f, 0.f);
 	{
-		// Conservative bounds of the pixels this Gaussian can blend into: alpha = opac * exp(-q/2) >= 1/255 needs
-		// q = d^T conic d <= 2 ln(255 opac); the AABB of that ellipse is centre +- sqrt(q_max * cov_xx|yy)
-		// (cov after the +0.3 low-pass).  5 % + 0.1 margin on q_max, 1 % + 1 px on the box.
-		const float inf = __int_as_float(0x7f800000);
+		// Cull record: alpha = opac * exp(-q/2) >= 1/255 needs q = d^T conic d <= q_max = 2 ln(255 opac); the record is
+		// that ellipse (5 % + 0.1 margin on q_max) normalised to d^T E d <= 1.  No disc part for this variant.
 		const float opac = opacities[idx] * h_convolution_scaling;
-		float4 bb = make_float4(inf, inf, -inf, -inf);
+		float4 c0 = make_float4(pix_x, pix_y, 0.f, 0.f), c1 = make_float4(0.f, 0.f, 0.f, -2.0f);
 		if (opac >= 1.0f / 255.0f) {
-			const float c2 = 2.0f * logf(255.0f * opac) * 1.05f + 0.1f;
-			const float hx = sqrtf(c2 * cx) * 1.01f + 1.0f, hy = sqrtf(c2 * cz) * 1.01f + 1.0f;
-			bb = make_float4(pix_x - hx, pix_y - hy, pix_x + hx, pix_y + hy);
+			const float inv_q = 1.0f / (2.0f * logf(255.0f * opac) * 1.05f + 0.1f);
+			c0.z = conx * inv_q; c0.w = cony * inv_q; c1.x = conz * inv_q; c1.w = -1.0f;
 		}
-		g.bbox[idx] = bb;
+		g.bbox[2 * idx] = c0;
+		g.bbox[2 * idx + 1] = c1;
 	}
 	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
 }
@@ -231,8 +229,7 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		if (hit) {
 			id = point_list[range.x + (uint32_t)(base + lane)];
 			if (cull) {
-				const float4 bb = bbox[id];
-				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
@@ -355,8 +352,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		if (hit) {
 			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
 			if (cull) {
-				const float4 bb = bbox[id];
-				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);

@@ -67,8 +67,9 @@ struct GeomState {
 	uint32_t* point_offsets; // P        inclusive scan
 	uint8_t* clamped;        // P        bit c set = SH colour channel c clamped at 0
 	float4* rec;             // P*REC_F4
-	float4* bbox;            // P        conservative screen-space bounds (xmin,ymin,xmax,ymax) of the pixels a
-	                         //          Gaussian can blend into; used for per-wave culling in the tile kernels
+	float4* bbox;            // 2P       cull record: conservative screen-space footprint of the pixels a Gaussian can
+	                         //          blend into, {ex, ey, a, b}{c, disc_x, disc_y, disc_r2}: ellipse d^T[[a,b],[b,c]]d <= 1
+	                         //          about (ex,ey) united with a disc; see cull_hit() below
 	float* aux;              // G: cov3D P*6.  S: unused
 	float* acc;              // backward accumulator P*ACC_F (zeroed by backward)
 	int* flags;              // 4 ints: [0] prefiltered-trap flag
@@ -240,6 +241,42 @@ __device__ __forceinline__ float div_nr(float a, float b) {
 	const float q = a * r;
 	const float e = fmaf(-b, q, a);
 	return fmaf(e, r, q);
+}
+
+
+// ---- per-wave culling vote.  A Gaussian's cull record (two float4, written by preprocess) describes a superset of
+// the pixels it can blend into: the ellipse d^T [[a,b],[b,c]] d <= 1 about (ex, ey), united with a disc of squared
+// radius r2 about (dcx, dcy).  Encodings: a <= 0 (or NaN) = unbounded (always a hit); r2 == -1 = no disc;
+// r2 == -2 = can never blend (opacity < 1/255).  The vote asks whether that set meets the wave's 8x8 pixel block
+// [x0,x1]x[y0,y1] (already inflated by half a pixel by the caller): the minimum of a convex quadratic over a box is
+// attained at the centre if it lies inside, otherwise on one of the four edges.  The vote runs once per (wave, list
+// entry) with one entry per lane, so its ~40 instructions cost less than one per entry.
+__device__ __forceinline__ bool cull_hit(const float4 c0, const float4 c1, float x0, float x1, float y0, float y1) {
+	if (c1.w == -2.0f) return false;
+	const float a = c0.z, b = c0.w, c = c1.x;
+	if (!(a > 0.0f)) return true;
+	const float ex = c0.x, ey = c0.y;
+	bool hit = ex >= x0 && ex <= x1 && ey >= y0 && ey <= y1;
+	if (!hit) {
+		float best = __int_as_float(0x7f800000);
+		const float boc = b / c, boa = b / a;
+#pragma unroll
+		for (int e = 0; e < 2; e++) {
+			const float dx = (e ? x1 : x0) - ex;
+			const float dy = fminf(fmaxf(-boc * dx, y0 - ey), y1 - ey);
+			best = fminf(best, a * dx * dx + 2.0f * b * dx * dy + c * dy * dy);
+			const float dy2 = (e ? y1 : y0) - ey;
+			const float dx2 = fminf(fmaxf(-boa * dy2, x0 - ex), x1 - ex);
+			best = fminf(best, a * dx2 * dx2 + 2.0f * b * dx2 * dy2 + c * dy2 * dy2);
+		}
+		hit = !(best > 1.0f);   // NaN -> hit
+	}
+	if (!hit && c1.w >= 0.0f) {
+		const float dx = fminf(fmaxf(c1.y, x0), x1) - c1.y;
+		const float dy = fminf(fmaxf(c1.z, y0), y1) - c1.z;
+		hit = !(dx * dx + dy * dy > c1.w);
+	}
+	return hit;
 }
 
 // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so

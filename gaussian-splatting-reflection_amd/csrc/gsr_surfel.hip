@@ -93,39 +93,50 @@ __device__ __forceinline__ void compute_transmat(float px, float py, float pz, c
 	normal = f3(vm[0] * nx + vm[4] * ny + vm[8] * nz, vm[1] * nx + vm[5] * ny + vm[9] * nz, vm[2] * nx + vm[6] * ny + vm[10] * nz);
 }
 
-// Conservative screen-space bounds of the pixels a surfel can blend into (alpha >= 1/255), for the per-wave
-// culling of the tile kernels.  alpha = min(0.99, opa * exp(-rho/2)) >= 1/255 needs rho <= rho_max =
-// 2 ln(255 opa), with rho = min(rho3d, rho2d):
-//   * rho3d <= c2: inside the projected ellipse u^2+v^2 <= c2 of the splat; its exact screen AABB is the
-//     compute_aabb formula of the reference (DSR forward.cu:119-145) evaluated at cutoff^2 = c2;
-//   * rho2d <= c2: inside the disc of radius sqrt(c2/2) about the low-pass centre (the cutoff-3 AABB centre).
-// c2 carries a 5 % + 0.1 margin over rho_max and the box 2 % + >= 1 px (the per-pixel evaluation of rho3d
-// cancels catastrophically, ~1e-4 relative).  If the cutoff circle reaches the camera plane (d >= 0) the
-// projection is unbounded and the box is infinite; opa < 1/255 can never blend and the box is empty.
-// Culling with these bounds leaves every output bit-identical (tests/test_gpu_parity.py::test_cull_*).
-__device__ __forceinline__ float4 surfel_bbox(const M3& T, float cx, float cy, float opa) {
-	const float inf = __int_as_float(0x7f800000);
-	if (!(opa >= 1.0f / 255.0f)) return make_float4(inf, inf, -inf, -inf);
-	const float rho_max = 2.0f * logf(255.0f * opa);
-	const float c2 = rho_max * 1.05f + 0.1f;
-	float x0 = -inf, y0 = -inf, x1 = inf, y1 = inf;
-	const float tw2 = T.m[2][2] * T.m[2][2];
-	const float d = c2 * (T.m[2][0] * T.m[2][0] + T.m[2][1] * T.m[2][1]) - tw2;
-	if (d < -1e-5f * tw2) {
-		const float fa = c2 / d, fb = -1.0f / d;
-		const float px = fa * (T.m[0][0] * T.m[2][0] + T.m[0][1] * T.m[2][1]) + fb * (T.m[0][2] * T.m[2][2]);
-		const float py = fa * (T.m[1][0] * T.m[2][0] + T.m[1][1] * T.m[2][1]) + fb * (T.m[1][2] * T.m[2][2]);
-		const float hx2 = px * px - (fa * (T.m[0][0] * T.m[0][0] + T.m[0][1] * T.m[0][1]) + fb * (T.m[0][2] * T.m[0][2]));
-		const float hy2 = py * py - (fa * (T.m[1][0] * T.m[1][0] + T.m[1][1] * T.m[1][1]) + fb * (T.m[1][2] * T.m[1][2]));
-		const float hx = sqrtf(fmaxf(hx2, 0.f)) * 1.02f + 1.0f + 1e-3f * fabsf(px);
-		const float hy = sqrtf(fmaxf(hy2, 0.f)) * 1.02f + 1.0f + 1e-3f * fabsf(py);
-		x0 = px - hx; x1 = px + hx; y0 = py - hy; y1 = py + hy;
-	}
-	const float r = sqrtf(0.5f * c2) + 1.0f;
-	x0 = fminf(x0, cx - r); x1 = fmaxf(x1, cx + r);
-	y0 = fminf(y0, cy - r); y1 = fmaxf(y1, cy + r);
-	// NaN anywhere -> comparisons in the kernels evaluate to "hit" (conservative)
-	return make_float4(x0, y0, x1, y1);
+// Cull record of a surfel (see cull_hit() in gsr_internal.hpp): a superset of the pixels it can blend into.
+// alpha = min(0.99, opa * exp(-rho/2)) >= 1/255 needs rho <= rho_max = 2 ln(255 opa), rho = min(rho3d, rho2d):
+//   * rho3d <= c2 is the image of the splat-space disc u^2+v^2 <= c2 under the homography pix_h = A (u,v,1)^T,
+//     A = rows (Tu, Tv, Tw): the conic x^T C x <= 0 with C = A^-T diag(1,1,-c2) A^-1, i.e. (when the disc stays in
+//     front of the camera plane) an ellipse; its centre and shape matrix are extracted here in double precision
+//     (the adjugate products cancel heavily in fp32) and stored normalised to d^T E d <= 1;
+//   * rho2d <= c2 is the disc of squared radius c2/2 about the low-pass centre (the cutoff-3 AABB centre).
+// c2 carries a 5 % + 0.1 margin over rho_max, the ellipse another 2 %; the per-pixel evaluation of rho3d itself is
+// only good to ~1e-4 relative.  Anything irregular (disc reaching the camera plane, non-ellipse conic, NaN) is
+// encoded as "always a hit"; opa < 1/255 can never blend.  Culling with this record leaves every output
+// bit-identical (tests/test_gpu_parity.py::test_cull_is_bit_exact).
+__device__ __forceinline__ void surfel_cull_record(const M3& T, float cx, float cy, float opa, float4& c0, float4& c1) {
+	c0 = make_float4(cx, cy, 0.f, 0.f);
+	c1 = make_float4(0.f, cx, cy, -2.0f);
+	if (!(opa >= 1.0f / 255.0f)) return;   // never
+	const float c2f = 2.0f * logf(255.0f * opa) * 1.05f + 0.1f;
+	c1.w = 0.5f * c2f * 1.02f;             // disc about the low-pass centre
+	const double c2 = (double)c2f;
+	const double a00 = T.m[0][0], a01 = T.m[0][1], a02 = T.m[0][2];   // Tu
+	const double a10 = T.m[1][0], a11 = T.m[1][1], a12 = T.m[1][2];   // Tv
+	const double a20 = T.m[2][0], a21 = T.m[2][1], a22 = T.m[2][2];   // Tw
+	// the cutoff disc must stay strictly in front of the camera plane (w > 0), else the projection is unbounded
+	if (!(c2 * (a20 * a20 + a21 * a21) - a22 * a22 < -1e-6 * a22 * a22)) return;   // a stays 0: always a hit
+	// adjugate of A (inverse up to the factor det, which only rescales the conic)
+	const double j00 = a11 * a22 - a12 * a21, j01 = a02 * a21 - a01 * a22, j02 = a01 * a12 - a02 * a11;
+	const double j10 = a12 * a20 - a10 * a22, j11 = a00 * a22 - a02 * a20, j12 = a02 * a10 - a00 * a12;
+	const double j20 = a10 * a21 - a11 * a20, j21 = a01 * a20 - a00 * a21, j22 = a00 * a11 - a01 * a10;
+	// C = adj^T diag(1,1,-c2) adj
+	const double C00 = j00 * j00 + j10 * j10 - c2 * j20 * j20;
+	const double C01 = j00 * j01 + j10 * j11 - c2 * j20 * j21;
+	const double C11 = j01 * j01 + j11 * j11 - c2 * j21 * j21;
+	const double C02 = j00 * j02 + j10 * j12 - c2 * j20 * j22;
+	const double C12 = j01 * j02 + j11 * j12 - c2 * j21 * j22;
+	const double C22 = j02 * j02 + j12 * j12 - c2 * j22 * j22;
+	const double det2 = C00 * C11 - C01 * C01;
+	if (!(det2 > 0.0) || !(C00 > 0.0)) return;
+	const double ex = -(C11 * C02 - C01 * C12) / det2, ey = -(C00 * C12 - C01 * C02) / det2;
+	const double q0 = C22 + C02 * ex + C12 * ey;
+	if (!(q0 < 0.0)) return;
+	const double sc = 1.0 / (-q0 * 1.02);
+	const float fa = (float)(C00 * sc), fb = (float)(C01 * sc), fc = (float)(C11 * sc);
+	if (!(fa > 0.f) || !(fc > 0.f) || !(fa * fc - fb * fb > 0.f) || !(fabsf((float)ex) < 1e7f) || !(fabsf((float)ey) < 1e7f)) return;
+	c0 = make_float4((float)ex, (float)ey, fa, fb);
+	c1.x = fc;
 }
 
 // preprocessCUDA forward (DSR forward.cu:149-253); FMA contraction off (integer outputs bit-exact vs oracle).
@@ -200,7 +211,12 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
 	const float maskv = (env_scope_mask != nullptr && env_scope_mask[idx]) ? 1.0f : 0.0f;
-	g.bbox[idx] = surfel_bbox(T, pxi, pyi, opacities[idx]);
+	{
+		float4 c0, c1;
+		surfel_cull_record(T, pxi, pyi, opacities[idx], c0, c1);
+		g.bbox[2 * idx] = c0;
+		g.bbox[2 * idx + 1] = c1;
+	}
 	float4* rec = g.rec + (size_t)idx * S_REC_F4;
 	rec[0] = make_float4(pxi, pyi, T.m[0][0], T.m[0][1]);
 	rec[1] = make_float4(T.m[0][2], T.m[1][0], T.m[1][1], T.m[1][2]);
@@ -295,8 +311,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		if (hit) {
 			id = point_list[range.x + (uint32_t)(base + lane)];
 			if (cull) {
-				const float4 bb = bbox[id];
-				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
@@ -552,8 +567,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		if (hit) {
 			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
 			if (cull) {
-				const float4 bb = bbox[id];
-				hit = !(bb.z < qx0 || bb.x > qx1 || bb.w < qy0 || bb.y > qy1);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
