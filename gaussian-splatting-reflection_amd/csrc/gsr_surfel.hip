@@ -230,7 +230,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 // tile kernels (DSR forward.cu:362-410, backward.cu:292-336).  EPS is the `unstable` threshold: 1e-4 in
 // the forward, 1e-6 in the backward — a quirk of the reference that is reproduced on purpose.
 struct SurfelPair {
-	float kx, ky, kz, lx, ly, lz, pz, sx, sy, dx, dy, rho3d, rho2d, depth, G, alpha;
+	float kx, ky, kz, lx, ly, lz, pz, inv_pz, sx, sy, dx, dy, rho3d, rho2d, depth, G, alpha;
 };
 template <bool FWD>
 __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, const float4 r2, float opac, float pixx, float pixy, SurfelPair& o) {
@@ -247,9 +247,9 @@ __device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, co
 	// straight-line code (selects, no early returns): fewer exec-mask branches in the hot loop.  (Evaluating two list
 	// entries per iteration so that the scheduler can interleave two of these chains was tried and measured 3 % slower.)
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
-	const float inv_pz = div_nr(1.0f, unstable ? 1.0f : o.pz);  // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale)
-	o.sx = unstable ? 0.f : ppx * inv_pz;
-	o.sy = unstable ? 0.f : ppy * inv_pz;
+	o.inv_pz = div_nr(1.0f, unstable ? 1.0f : o.pz);  // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale)
+	o.sx = unstable ? 0.f : ppx * o.inv_pz;
+	o.sy = unstable ? 0.f : ppy * o.inv_pz;
 	o.rho3d = unstable ? 1e8f : (o.sx * o.sx + o.sy * o.sy);
 	o.dx = r0.x - pixx;
 	o.dy = r0.y - pixy;
@@ -411,11 +411,11 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 // renderCUDA backward (DSR backward.cu:143-470).
 // Per-pixel recursion state of the back-to-front traversal + this pixel's upstream gradients.
 struct SurfelBwdPix {
-	float T, T_final, final_D, final_D2, final_A, last_dL_dT, bg_dot_dpixel;
+	float T, T_final, last_dL_dT, bg_dot_dpixel;
 	int last_contributor, median_contributor;
-	float dp0, dp1, dp2, dr, dL_dreg, dL_ddepth, dL_daccum, dnx, dny, dnz, dL_dmedian_depth;
-	float acc_c0, acc_c1, acc_c2, acc_r, acc_depth, acc_alpha, acc_n0, acc_n1, acc_n2;
-	float last_alpha, lc0, lc1, lc2, lr, last_depth, ln0, ln1, ln2;
+	float dp0, dp1, dp2, dr, dL_ddepth, dL_daccum, dnx, dny, dnz, dL_dmedian_depth;
+	float FD2r, FAr, FDr;          // final_D2, final_A, final_D times dL_dreg
+	float A, Dprev, last_alpha;    // blended <attributes, upstream grads> behind this pixel's current position
 };
 __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, size_t pix, size_t HW, const float* __restrict__ bg,
                                                 const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
@@ -426,7 +426,8 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 	s.last_contributor = inside ? (int)n_contrib[pix] : 0;
 	s.median_contributor = inside ? (int)n_contrib[HW + pix] : 0;
 	s.dp0 = s.dp1 = s.dp2 = s.dr = 0.f;
-	s.dL_dreg = s.dL_ddepth = s.dL_daccum = s.dnx = s.dny = s.dnz = s.dL_dmedian_depth = 0.f;
+	s.dL_ddepth = s.dL_daccum = s.dnx = s.dny = s.dnz = s.dL_dmedian_depth = 0.f;
+	float dL_dreg = 0.f;
 	if (inside) {
 		s.dp0 = dL_dpixels[pix]; s.dp1 = dL_dpixels[HW + pix]; s.dp2 = dL_dpixels[2 * HW + pix];
 		s.dr = dL_drefl_map[pix];
@@ -434,82 +435,80 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 		s.dL_daccum = dL_depths[1 * HW + pix];
 		s.dnx = dL_depths[2 * HW + pix]; s.dny = dL_depths[3 * HW + pix]; s.dnz = dL_depths[4 * HW + pix];
 		s.dL_dmedian_depth = dL_depths[5 * HW + pix];
-		s.dL_dreg = dL_depths[6 * HW + pix];
+		dL_dreg = dL_depths[6 * HW + pix];
 	}
-	s.final_D = inside ? final_Ts[HW + pix] : 0.f;
-	s.final_D2 = inside ? final_Ts[2 * HW + pix] : 0.f;
-	s.final_A = 1 - s.T_final;
+	s.FDr = (inside ? final_Ts[HW + pix] : 0.f) * dL_dreg;
+	s.FD2r = (inside ? final_Ts[2 * HW + pix] : 0.f) * dL_dreg;
+	s.FAr = (1 - s.T_final) * dL_dreg;
 	s.last_dL_dT = 0;
-	s.acc_c0 = s.acc_c1 = s.acc_c2 = s.acc_r = s.acc_depth = s.acc_alpha = s.acc_n0 = s.acc_n1 = s.acc_n2 = 0.f;
-	s.last_alpha = s.lc0 = s.lc1 = s.lc2 = s.lr = s.last_depth = s.ln0 = s.ln1 = s.ln2 = 0.f;
+	s.A = s.Dprev = s.last_alpha = 0.f;
 	s.bg_dot_dpixel = bg[0] * s.dp0 + bg[1] * s.dp1 + bg[2] * s.dp2;
 }
-// One contributing (pixel, surfel) pair: advances the recursion and writes the 19 gradient contributions
-// (slots SA_*) into v.  Text follows DSR backward.cu:338-467.
-__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, const float4 r2, const float4 r3, const float4 r4,
-                                                int contributor, float pixx, float pixy, float* v) {
-	const float alpha = o.alpha, G = o.G, c_d = o.depth;
+// One (pixel, surfel) pair of the back-to-front recursion (DSR backward.cu:338-467): advances the per-pixel state and
+// writes the 19 gradient contributions (slots SA_*) into v.  Straight-line for all 64 lanes:
+//   * a lane whose pair does not contribute (`ok` false) runs with alpha = 0, which is the identity of every
+//     recurrence below (T/(1-0), blend weights 0), and has its two root gradients zeroed, so all of v comes out 0
+//     without exec-mask regions or a zero-fill of v;
+//   * the reference keeps, per output channel x, accum_rec_x = last_alpha*last_x + (1-last_alpha)*accum_rec_x and adds
+//     (x - accum_rec_x)*dL_dx to dL_dalpha; only the dot product over channels is ever used, and the recurrence is
+//     linear, so ONE scalar recurrence A over D = <attributes, upstream grads> replaces the nine (same value up
+//     to summation order);
+//   * 1/(1-alpha), 1/depth and 1/p.z are formed once (Newton-refined v_rcp) and multiplied through.
+__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, bool ok, const float4 r2, const float4 r3,
+                                                const float4 r4, int contributor, float pixx, float pixy, float* v) {
+	const float alpha = ok ? o.alpha : 0.f;
+	const float c_d = ok ? o.depth : 1.0f;
+	// a rejected pair may carry inf/NaN here (s overflows when the ray grazes the splat plane); 0 * that must stay 0
+	const float G = ok ? o.G : 0.f, sx = ok ? o.sx : 0.f, sy = ok ? o.sy : 0.f;
 	const float Twx = r2.x, Twy = r2.y;
-	s.T = div_nr(s.T, 1.f - alpha);
+	const float inv_1ma = div_nr(1.0f, 1.f - alpha);
+	s.T *= inv_1ma;
 	const float T = s.T;
-	const float dchannel_dcolor = alpha * T;
-	const float last_alpha = s.last_alpha;
-	float dL_dalpha = 0.0f;
-	s.acc_c0 = last_alpha * s.lc0 + (1.f - last_alpha) * s.acc_c0; s.lc0 = r3.w; dL_dalpha += (r3.w - s.acc_c0) * s.dp0;
-	s.acc_c1 = last_alpha * s.lc1 + (1.f - last_alpha) * s.acc_c1; s.lc1 = r4.x; dL_dalpha += (r4.x - s.acc_c1) * s.dp1;
-	s.acc_c2 = last_alpha * s.lc2 + (1.f - last_alpha) * s.acc_c2; s.lc2 = r4.y; dL_dalpha += (r4.y - s.acc_c2) * s.dp2;
-	v[SA_COLOR + 0] = dchannel_dcolor * s.dp0;
-	v[SA_COLOR + 1] = dchannel_dcolor * s.dp1;
-	v[SA_COLOR + 2] = dchannel_dcolor * s.dp2;
-	s.acc_r = last_alpha * s.lr + (1.f - last_alpha) * s.acc_r; s.lr = r4.z;
-	dL_dalpha += (r4.z - s.acc_r) * s.dr;
-	v[SA_REFL] = dchannel_dcolor * s.dr;
-	float dL_dz = 0.0f, dL_dweight = 0.f;
-	const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(c_d));
-	const float dmd_dd = div_nr(S_FAR * S_NEAR, (S_FAR - S_NEAR) * c_d * c_d);
-	if (contributor == s.median_contributor - 1) dL_dz += s.dL_dmedian_depth;
-	dL_dweight += (s.final_D2 + m_d * m_d * s.final_A - 2 * m_d * s.final_D) * s.dL_dreg;
+	const float w = alpha * T;
+	const float D = r3.w * s.dp0 + r4.x * s.dp1 + r4.y * s.dp2 + r4.z * s.dr + c_d * s.dL_ddepth + s.dL_daccum
+	              + r2.w * s.dnx + r3.x * s.dny + r3.y * s.dnz;
+	s.A = s.last_alpha * s.Dprev + (1.f - s.last_alpha) * s.A;
+	s.Dprev = D;
+	s.last_alpha = alpha;
+	float dL_dalpha = D - s.A;
+	v[SA_COLOR + 0] = w * s.dp0;
+	v[SA_COLOR + 1] = w * s.dp1;
+	v[SA_COLOR + 2] = w * s.dp2;
+	v[SA_REFL] = w * s.dr;
+	v[SA_NORMAL + 0] = w * s.dnx;
+	v[SA_NORMAL + 1] = w * s.dny;
+	v[SA_NORMAL + 2] = w * s.dnz;
+	// distortion regulariser
+	const float rc = div_nr(1.0f, c_d);
+	const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * rc);
+	const float dmd_dd = (S_FAR * S_NEAR / (S_FAR - S_NEAR)) * rc * rc;
+	const float dL_dweight = s.FD2r + m_d * (m_d * s.FAr - 2 * s.FDr);
 	dL_dalpha += dL_dweight - s.last_dL_dT;
 	s.last_dL_dT = dL_dweight * alpha + (1 - alpha) * s.last_dL_dT;
-	const float dL_dmd = 2.0f * (T * alpha) * (m_d * s.final_A - s.final_D) * s.dL_dreg;
-	dL_dz += dL_dmd * dmd_dd;
-	s.acc_depth = last_alpha * s.last_depth + (1.f - last_alpha) * s.acc_depth; s.last_depth = c_d;
-	dL_dalpha += (c_d - s.acc_depth) * s.dL_ddepth;
-	s.acc_alpha = last_alpha * 1.0f + (1.f - last_alpha) * s.acc_alpha;
-	dL_dalpha += (1 - s.acc_alpha) * s.dL_daccum;
-	s.acc_n0 = last_alpha * s.ln0 + (1.f - last_alpha) * s.acc_n0; s.ln0 = r2.w; dL_dalpha += (r2.w - s.acc_n0) * s.dnx;
-	s.acc_n1 = last_alpha * s.ln1 + (1.f - last_alpha) * s.acc_n1; s.ln1 = r3.x; dL_dalpha += (r3.x - s.acc_n1) * s.dny;
-	s.acc_n2 = last_alpha * s.ln2 + (1.f - last_alpha) * s.acc_n2; s.ln2 = r3.y; dL_dalpha += (r3.y - s.acc_n2) * s.dnz;
-	v[SA_NORMAL + 0] = alpha * T * s.dnx;
-	v[SA_NORMAL + 1] = alpha * T * s.dny;
-	v[SA_NORMAL + 2] = alpha * T * s.dnz;
+	const float dL_dmd = 2.0f * w * (m_d * s.FAr - s.FDr);
+	float dL_dz = dL_dmd * dmd_dd + w * s.dL_ddepth;
+	dL_dz += (contributor == s.median_contributor - 1) ? s.dL_dmedian_depth : 0.f;
 	dL_dalpha *= T;
-	s.last_alpha = alpha;
-	dL_dalpha += div_nr(-s.T_final, 1.f - alpha) * s.bg_dot_dpixel;
-	const float dL_dG = r3.z * dL_dalpha;
-	dL_dz += alpha * T * s.dL_ddepth;
-	if (o.rho3d <= o.rho2d) {
-		const float dL_dsx = dL_dG * -G * o.sx + dL_dz * Twx;
-		const float dL_dsy = dL_dG * -G * o.sy + dL_dz * Twy;
-		const float dsx_pz = div_nr(dL_dsx, o.pz), dsy_pz = div_nr(dL_dsy, o.pz);
-		const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * o.sx + dsy_pz * o.sy);
-		// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
-		const float dkx = o.ly * dpz - o.lz * dpy, dky = o.lz * dpx - o.lx * dpz, dkz = o.lx * dpy - o.ly * dpx;
-		const float dlx = dpy * o.kz - dpz * o.ky, dly = dpz * o.kx - dpx * o.kz, dlz = dpx * o.ky - dpy * o.kx;
-		v[SA_T + 0] = -dkx; v[SA_T + 1] = -dky; v[SA_T + 2] = -dkz;
-		v[SA_T + 3] = -dlx; v[SA_T + 4] = -dly; v[SA_T + 5] = -dlz;
-		v[SA_T + 6] = pixx * dkx + pixy * dlx + dL_dz * o.sx;
-		v[SA_T + 7] = pixx * dky + pixy * dly + dL_dz * o.sy;
-		v[SA_T + 8] = pixx * dkz + pixy * dlz + dL_dz * 1.0f;
-	} else {
-		const float dG_ddelx = -G * S_FILTER_INV_SQ * o.dx;
-		const float dG_ddely = -G * S_FILTER_INV_SQ * o.dy;
-		v[SA_MEAN2D + 0] = dL_dG * dG_ddelx;
-		v[SA_MEAN2D + 1] = dL_dG * dG_ddely;
-		v[SA_T + 6] = o.sx * dL_dz;
-		v[SA_T + 7] = o.sy * dL_dz;
-		v[SA_T + 8] = dL_dz;
-	}
+	dL_dalpha -= s.T_final * inv_1ma * s.bg_dot_dpixel;
+	dL_dalpha = ok ? dL_dalpha : 0.f;
+	dL_dz = ok ? dL_dz : 0.f;
+	const float nG = -G * (r3.z * dL_dalpha);   // dL_dG * -G
+	const bool use3d = o.rho3d <= o.rho2d;
+	const float dL_dsx = use3d ? nG * sx + dL_dz * Twx : 0.f;
+	const float dL_dsy = use3d ? nG * sy + dL_dz * Twy : 0.f;
+	const float dpx = dL_dsx * o.inv_pz, dpy = dL_dsy * o.inv_pz, dpz = -(dpx * sx + dpy * sy);
+	// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k); the T rows receive -dL_dk, -dL_dl and pix.x*dL_dk + pix.y*dL_dl.
+	// nk = -dL_dk, nl = -dL_dl are formed directly (operand order), the sign of the third row rides on source modifiers.
+	const float nkx = o.lz * dpy - o.ly * dpz, nky = o.lx * dpz - o.lz * dpx, nkz = o.ly * dpx - o.lx * dpy;
+	const float nlx = dpz * o.ky - dpy * o.kz, nly = dpx * o.kz - dpz * o.kx, nlz = dpy * o.kx - dpx * o.ky;
+	v[SA_T + 0] = nkx; v[SA_T + 1] = nky; v[SA_T + 2] = nkz;
+	v[SA_T + 3] = nlx; v[SA_T + 4] = nly; v[SA_T + 5] = nlz;
+	v[SA_T + 6] = dL_dz * sx - (pixx * nkx + pixy * nlx);
+	v[SA_T + 7] = dL_dz * sy - (pixx * nky + pixy * nly);
+	v[SA_T + 8] = dL_dz - (pixx * nkz + pixy * nlz);
+	const float g2 = use3d ? 0.f : nG * S_FILTER_INV_SQ;   // low-pass branch: gradient to the 2D centre only
+	v[SA_MEAN2D + 0] = g2 * o.dx;
+	v[SA_MEAN2D + 1] = g2 * o.dy;
 	v[SA_OPAC] = G * dL_dalpha;
 }
 
@@ -598,15 +597,17 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
 			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			SurfelPair o;
-			const bool ok = inside && contributor < st.last_contributor && surfel_pair<false>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			// evaluated for all 64 lanes (no short-circuit): the straight-line gradient code below multiplies every field of
+			// `o` by zero in rejected lanes, so the fields must be defined (finite) there too
+			const bool pair_ok = surfel_pair<false>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			const bool ok = inside && contributor < st.last_contributor && pair_ok;
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
 			__builtin_amdgcn_sched_barrier(0);
 			if (__ballot(ok) == 0ull) return;
 			float v[S_ACC_F];
-#pragma unroll
-			for (int q = 0; q < S_ACC_F; q++) v[q] = 0.f;
-			if (ok) surfel_bwd_pair(st, o, R.r2, R.r3, R.r4, contributor, pixx, pixy, v);
+			v[S_ACC_F - 1] = 0.f;
+			surfel_bwd_pair(st, o, ok, R.r2, R.r3, R.r4, contributor, pixx, pixy, v);
 			// 20 values -> 5 registers of 4 folded values -> row sums; lanes 15/31/47/63 park one value each
 			float z[5];
 #pragma unroll
