@@ -183,10 +183,10 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 	dy = r0.y - pixy;
 	const float q = fmaf(r0.z * dx, dx, (conz * dy) * dy);
 	const float power = fmaf(-0.5f, q, -((r0.w * dx) * dy));
-	if (power > 0.0f) return false;
+	// straight-line (no early return): G and alpha are defined in every lane, the callers zero them where the pair is rejected
 	G = __expf(power);
 	alpha = fminf(0.99f, opac * G);
-	return !(alpha < 1.0f / 255.0f);
+	return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
 }
 
 // renderCUDA forward (DGR forward.cu:274-411), wave-per-quadrant form (see surfel_render_fwd_wave_kernel in
@@ -249,33 +249,28 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		for (int k = 0; k < nh; k++) {
 			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
 			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
+			// straight-line for all 64 lanes: a rejected pair blends with weight 0 (see surfel_render_fwd_wave_kernel)
 			float dx, dy, G, alpha;
-			bool ok = !done && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+			const bool pair_ok = gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
 			if (k + 1 < nh) {
 				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
 			}
-			float test_T = 0.f;
-			if (ok) {
-				test_T = T * (1 - alpha);
-				if (test_T < 0.0001f) {
-					done = true;
-					ok = false;
-				}
-			}
+			const float test_T = T * (1 - alpha);
+			const bool live = !done && pair_ok;
+			const bool sat = live && test_T < 0.0001f;
+			const bool ok = live && !sat;
+			done = done || sat;
 			if (__ballot(ok) != 0ull) {
-				if (ok) {
-					const float w = alpha * T;
-					C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
-					N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
-					RS = fmaf(r3.x, w, RS);
-					if (INVDEPTH) ID = fmaf(r3.y, w, ID);
-					T = test_T;
-					last_contributor = contributor;
-				}
-			} else if (__ballot(!done) == 0ull) {
-				break;
+				const float w = ok ? alpha * T : 0.f;
+				C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
+				N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
+				RS = fmaf(r3.x, w, RS);
+				if (INVDEPTH) ID = fmaf(r3.y, w, ID);
+				T = ok ? test_T : T;
+				last_contributor = ok ? contributor : last_contributor;
 			}
+			if (__ballot(sat) != 0ull && __ballot(!done) == 0ull) break;
 		}
 	}
 	if (inside) {
@@ -328,7 +323,6 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
 	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-	float acc_c0 = 0, acc_c1 = 0, acc_c2 = 0, acc_n0 = 0, acc_n1 = 0, acc_n2 = 0, acc_r = 0, acc_i = 0;
 	float dp0 = 0, dp1 = 0, dp2 = 0, dn0 = 0, dn1 = 0, dn2 = 0, dr = 0, di = 0;
 	if (inside) {
 		dp0 = dL_dpixels[pix]; dp1 = dL_dpixels[HW + pix]; dp2 = dL_dpixels[2 * HW + pix];
@@ -336,7 +330,13 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		dr = dL_drefl_map[pix];
 		if (INVDEPTH) di = dL_invdepths[pix];
 	}
-	float last_alpha = 0, lc0 = 0, lc1 = 0, lc2 = 0, ln0 = 0, ln1 = 0, ln2 = 0, lr = 0, li = 0;
+	// The reference keeps accum_rec_x = last_alpha*last_x + (1-last_alpha)*accum_rec_x per output channel and adds
+	// (x - accum_rec_x)*dL_dx to dL_dalpha.  Only dot products over channels are used and the recurrence is linear,
+	// so two scalar recurrences replace the eight: A1 over D1 = <attributes, upstream grads> (-> dL_dalpha) and A2
+	// over D2, the same dot with colour weights 3,2,1 and no other channels: the reference's dL_dalpha_means2d is the
+	// running sum of the partial dL_dalpha INSIDE its colour loop (DGR backward.cu:613-614), i.e. 3 t0 + 2 t1 + t2.
+	float A1 = 0, A2 = 0, D1p = 0, D2p = 0, last_alpha = 0;
+	const float dp0x3 = 3.0f * dp0, dp1x2 = 2.0f * dp1;
 	const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 	const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
 
@@ -372,64 +372,52 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		for (int k = 0; k < nh; k++) {
 			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
 			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
-			float dx, dy, G, alpha;
-			const bool ok = inside && contributor < last_contributor && gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
+			float dx, dy, Gp, alpha_p;
+			const bool pair_ok = gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, Gp, alpha_p);   // all lanes: fields must be defined
+			const bool ok = inside && contributor < last_contributor && pair_ok;
 			if (k + 1 < nh) {
 				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
 			}
 			if (__ballot(ok) == 0ull) continue;
+			// Straight-line for all 64 lanes: a rejected pair runs with alpha = 0 (the identity of the recurrences) and
+			// G = 0, and has its root gradients zeroed, so every v[] comes out 0 without exec-mask regions.
 			float v[G_ACC_F];
-#pragma unroll
-			for (int q = 0; q < G_ACC_F; q++) v[q] = 0.f;
-			if (ok) {
-				T = div_nr(T, 1.f - alpha);
-				const float dchannel_dcolor = alpha * T;
-				float dL_dalpha = 0.0f, dL_dalpha_means2d = 0.0f;
-				// colour channels; dL_dalpha_means2d is the running sum INSIDE the loop (DGR backward.cu:613-614)
-				acc_c0 = last_alpha * lc0 + (1.f - last_alpha) * acc_c0; lc0 = r1.z;
-				dL_dalpha += (r1.z - acc_c0) * dp0; dL_dalpha_means2d += dL_dalpha;
-				acc_c1 = last_alpha * lc1 + (1.f - last_alpha) * acc_c1; lc1 = r1.w;
-				dL_dalpha += (r1.w - acc_c1) * dp1; dL_dalpha_means2d += dL_dalpha;
-				acc_c2 = last_alpha * lc2 + (1.f - last_alpha) * acc_c2; lc2 = r2.x;
-				dL_dalpha += (r2.x - acc_c2) * dp2; dL_dalpha_means2d += dL_dalpha;
-				v[GA_COLOR + 0] = dchannel_dcolor * dp0;
-				v[GA_COLOR + 1] = dchannel_dcolor * dp1;
-				v[GA_COLOR + 2] = dchannel_dcolor * dp2;
-				acc_n0 = last_alpha * ln0 + (1.f - last_alpha) * acc_n0; ln0 = r2.y; dL_dalpha += (r2.y - acc_n0) * dn0;
-				acc_n1 = last_alpha * ln1 + (1.f - last_alpha) * acc_n1; ln1 = r2.z; dL_dalpha += (r2.z - acc_n1) * dn1;
-				acc_n2 = last_alpha * ln2 + (1.f - last_alpha) * acc_n2; ln2 = r2.w; dL_dalpha += (r2.w - acc_n2) * dn2;
-				v[GA_NORMAL + 0] = dchannel_dcolor * dn0;
-				v[GA_NORMAL + 1] = dchannel_dcolor * dn1;
-				v[GA_NORMAL + 2] = dchannel_dcolor * dn2;
-				acc_r = last_alpha * lr + (1.f - last_alpha) * acc_r; lr = r3.x;
-				dL_dalpha += (r3.x - acc_r) * dr;
-				v[GA_REFL] = dchannel_dcolor * dr;
-				if (INVDEPTH) {
-					acc_i = last_alpha * li + (1.f - last_alpha) * acc_i; li = r3.y;
-					dL_dalpha += (r3.y - acc_i) * di;
-					v[GA_INVD] = dchannel_dcolor * di;
-				}
-				dL_dalpha *= T;
-				dL_dalpha_means2d *= T;
-				last_alpha = alpha;
-				const float bgterm = div_nr(-T_final, 1.f - alpha) * bg_dot_dpixel;
-				dL_dalpha += bgterm;
-				dL_dalpha_means2d += bgterm;
-				const float dL_dG = r1.y * dL_dalpha;
-				const float dL_dG_means2d = r1.y * dL_dalpha_means2d;
-				const float gdx = G * dx, gdy = G * dy;
-				const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-				const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-				v[GA_MEAN2D + 0] = dL_dG * dG_ddelx * ddelx_dx;
-				v[GA_MEAN2D + 1] = dL_dG * dG_ddely * ddely_dy;
-				v[GA_MEAN2DP + 0] = dL_dG_means2d * dG_ddelx * ddelx_dx;
-				v[GA_MEAN2DP + 1] = dL_dG_means2d * dG_ddely * ddely_dy;
-				v[GA_CONIC + 0] = -0.5f * gdx * dx * dL_dG;
-				v[GA_CONIC + 1] = -0.5f * gdx * dy * dL_dG;
-				v[GA_CONIC + 2] = -0.5f * gdy * dy * dL_dG;
-				v[GA_OPAC] = G * dL_dalpha;
-			}
+			const float alpha = ok ? alpha_p : 0.f, G = ok ? Gp : 0.f;
+			const float inv_1ma = div_nr(1.0f, 1.f - alpha);
+			T *= inv_1ma;
+			const float w = alpha * T;
+			float D1 = r1.z * dp0 + r1.w * dp1 + r2.x * dp2 + r2.y * dn0 + r2.z * dn1 + r2.w * dn2 + r3.x * dr;
+			if (INVDEPTH) D1 += r3.y * di;
+			const float D2 = r1.z * dp0x3 + r1.w * dp1x2 + r2.x * dp2;
+			A1 = last_alpha * D1p + (1.f - last_alpha) * A1;
+			A2 = last_alpha * D2p + (1.f - last_alpha) * A2;
+			D1p = D1; D2p = D2; last_alpha = alpha;
+			const float bgterm = -T_final * inv_1ma * bg_dot_dpixel;
+			const float dL_dalpha = ok ? (D1 - A1) * T + bgterm : 0.f;
+			const float dL_dalpha_means2d = ok ? (D2 - A2) * T + bgterm : 0.f;
+			v[GA_COLOR + 0] = w * dp0;
+			v[GA_COLOR + 1] = w * dp1;
+			v[GA_COLOR + 2] = w * dp2;
+			v[GA_NORMAL + 0] = w * dn0;
+			v[GA_NORMAL + 1] = w * dn1;
+			v[GA_NORMAL + 2] = w * dn2;
+			v[GA_REFL] = w * dr;
+			v[GA_INVD] = INVDEPTH ? w * di : 0.f;
+			const float dL_dG = r1.y * dL_dalpha;
+			const float dL_dG_means2d = r1.y * dL_dalpha_means2d;
+			const float gdx = G * dx, gdy = G * dy;
+			const float dG_ddelx = (-gdx * r0.z - gdy * r0.w) * ddelx_dx;
+			const float dG_ddely = (-gdy * r1.x - gdx * r0.w) * ddely_dy;
+			v[GA_MEAN2D + 0] = dL_dG * dG_ddelx;
+			v[GA_MEAN2D + 1] = dL_dG * dG_ddely;
+			v[GA_MEAN2DP + 0] = dL_dG_means2d * dG_ddelx;
+			v[GA_MEAN2DP + 1] = dL_dG_means2d * dG_ddely;
+			const float hg = -0.5f * dL_dG;
+			v[GA_CONIC + 0] = hg * gdx * dx;
+			v[GA_CONIC + 1] = hg * gdx * dy;
+			v[GA_CONIC + 2] = hg * gdy * dy;
+			v[GA_OPAC] = G * dL_dalpha;
 			float z[4];
 #pragma unroll
 			for (int g = 0; g < 4; g++) z[g] = fold4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);

@@ -208,18 +208,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 	v = dpp_add<0x143, 0xC>(v);
 	return v;  // total in lane 63
 }
-__device__ __forceinline__ float wave_max_pos(float v) {  // max over lanes of non-negative values; total in lane 63
-	int m;
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, false); v = fmaxf(v, __int_as_float(m));
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); v = fmaxf(v, __int_as_float(m));
-	m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); v = fmaxf(v, __int_as_float(m));
+// max over the wave of non-negative values; result in lane 63.  Fused v_max_f32_dpp steps (the compiler emits
+// v_mov_b32_dpp + two canonicalising v_max per step, 5 instructions, for the builtin form); out-of-row reads are 0
+// (bound_ctrl:0), which is the identity for non-negative inputs.  Must be called with all 64 lanes active.
+#define GSR_MAX1(CTRL) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\t"
+__device__ __forceinline__ float wave_max_pos(float v) {
+	asm volatile(GSR_MAX1(GSR_SHR1) GSR_MAX1(GSR_SHR2) GSR_MAX1(GSR_SHR4) GSR_MAX1(GSR_SHR8) GSR_MAX1(GSR_BC15) GSR_MAX1(GSR_BC31) : "+v"(v));
 	return v;
 }
-
-
 
 // exp(x) for x in [-88, 0]: exp2 of a two-float product x*log2(e) (hi from the multiply, lo from the FMA residual
 // plus the low word of log2(e)) with a first-order correction for lo.  ~1.5 ulp, 5 instructions; the plain

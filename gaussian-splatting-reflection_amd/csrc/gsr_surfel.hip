@@ -332,48 +332,44 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		for (int k = 0; k < nh; k++) {
 			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4;
 			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
+			// straight-line for all 64 lanes: a lane whose pair does not contribute blends with weight 0 (the identity of
+			// every accumulator) instead of sitting out in an exec-mask region
 			SurfelPair o;
-			bool ok = !done && surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
+			const bool pair_ok = surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
 			if (k + 1 < nh) {
 				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * S_REC_F4;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
 			}
-			float test_T = 0.f;
-			if (ok) {
-				test_T = T * (1 - o.alpha);
-				if (test_T < 0.0001f) {
-					done = true;
-					ok = false;
-				}
-			}
+			const float test_T = T * (1 - o.alpha);
+			const bool live = !done && pair_ok;
+			const bool sat = live && test_T < 0.0001f;   // this pixel is saturated: the pair is dropped and the pixel retires
+			const bool ok = live && !sat;
+			done = done || sat;
 			if (__ballot(ok) != 0ull) {
-				float w = 0.f;
-				if (ok) {
-					w = o.alpha * T;
-					const float A = 1 - T;
-					const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(o.depth));
-					distortion += (m * m * A + M2 - 2 * m * M1) * w;
-					Dp += o.depth * w;
-					M1 += m * w;
-					M2 += m * m * w;
-					if (T > 0.5f) {
-						median_depth = o.depth;
-						median_contributor = (float)contributor;
-					}
-					N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
-					C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
-					RS = fmaf(r4.z, w, RS);
-					if (r4.w != 0.f) mask = 1.0f;
-					T = test_T;
-					last_contributor = contributor;
-				}
+				const float w = ok ? o.alpha * T : 0.f;
+				const float depth = ok ? o.depth : 1.0f;
+				const float A = 1 - T;
+				const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(depth));
+				const float mw = m * w;
+				distortion += (m * m * A + M2 - 2 * m * M1) * w;
+				Dp += depth * w;
+				M1 += mw;
+				M2 += m * mw;
+				const bool med = ok && T > 0.5f;
+				median_depth = med ? depth : median_depth;
+				median_contributor = med ? (float)contributor : median_contributor;
+				N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
+				C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
+				RS = fmaf(r4.z, w, RS);
+				mask = (ok && r4.w != 0.f) ? 1.0f : mask;
+				T = ok ? test_T : T;
+				last_contributor = ok ? contributor : last_contributor;
 				// gaussian_weights (forward.cu:458-459): max over the wave's pixels; merged across waves by atomicMax
 				const float wm = wave_max_pos(w);
 				if (lane == 63) s_wmax[k] = wm;
 				touched |= 1ull << k;
-			} else if (__ballot(!done) == 0ull) {
-				break;
 			}
+			if (__ballot(sat) != 0ull && __ballot(!done) == 0ull) break;
 		}
 		__syncthreads();
 		// ---- 3. w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
