@@ -120,8 +120,12 @@ def main():
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
 
+    # the rasterizer's backward writes its parameter gradients straight into the flat all-reduce buffer
+    sink = scene.grads.sink()
+    rasterizer.set_grad_sink(sink)
+
     def step():
-        scene.flat_grad.zero_()
+        scene.grads.zero_except_(sink)     # cubemap + fail value are still accumulated by autograd
         means2D.grad = None
         final, allmap = forward()
         torch.autograd.backward([final, allmap], [g_final, g_allmap])

@@ -1,0 +1,284 @@
+// Training-step kernels around the rasterizer: the photometric loss of the reference's
+// train loop (train.py:167-173: (1 - lambda) * L1 + lambda * (1 - SSIM), utils/loss_utils.py:40-97) and the Adam update
+// of its eight parameter groups (scene/gaussian_model.py:196-209, torch.optim.Adam(lr=0, eps=1e-15)).
+//
+// Both are streaming, HBM-bound passes:
+//   * SSIM + L1: one 16x16 output tile per workgroup; the 26x26 halo of both images is staged in LDS once, the 11x11
+//     Gaussian window (sigma 1.5, zero padding 5: F.conv2d(padding=5, groups=C)) is applied separably to the five moment
+//     planes x, y, x^2, y^2, xy from LDS, and the kernel leaves only what the backward needs: the three partial-derivative
+//     planes of the SSIM map and two block-reduced sums.  ~8 B read + 12 B written per pixel-channel.
+//   * Adam: one float4 per lane over ONE flat parameter / gradient / moment buffer (28 B per parameter), learning rate
+//     by segment table, so the 59 floats per Gaussian + cubemap update in a single launch.
+#include <cstring>
+#include "gsr_internal.hpp"
+
+namespace gsr {
+
+#define SSIM_R 5
+#define SSIM_T 16
+#define SSIM_HALO (SSIM_T + 2 * SSIM_R)   // 26
+
+struct SsimWindow { float g[2 * SSIM_R + 1]; };
+
+// utils/loss_utils.py:46-48: exp(-(x - 5)^2 / (2 sigma^2)) as float32, normalised by the float32 sum
+static SsimWindow make_window() {
+	SsimWindow w;
+	float sum = 0.f;
+	for (int i = 0; i < 11; i++) {
+		w.g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+		sum += w.g[i];
+	}
+	for (int i = 0; i < 11; i++) w.g[i] /= sum;
+	return w;
+}
+
+// Stage the zero-padded halo tile of one plane pair into LDS.
+__device__ __forceinline__ void ssim_load_tile(const float* __restrict__ a, const float* __restrict__ b, int H, int W, int x0, int y0,
+                                               float (*ta)[SSIM_HALO + 1], float (*tb)[SSIM_HALO + 1]) {
+	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_HALO; i += 256) {
+		const int ly = i / SSIM_HALO, lx = i - ly * SSIM_HALO;
+		const int gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
+		const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+		const size_t o = (size_t)gy * W + gx;
+		ta[ly][lx] = in ? a[o] : 0.f;
+		tb[ly][lx] = in ? b[o] : 0.f;
+	}
+}
+
+// Forward: per-pixel SSIM (utils/loss_utils.py:75-92) and |x - y|, block-reduced into sums[0] (L1) and sums[1] (SSIM);
+// optionally the SSIM map and the three planes d ssim / d mu1, d ssim / d E[x^2], d ssim / d E[xy] for the backward.
+__global__ void __launch_bounds__(256)
+ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimWindow win, float C1, float C2,
+                   float* __restrict__ sums, float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                   float* __restrict__ dm_dsigma12) {
+	__shared__ float ta[SSIM_HALO][SSIM_HALO + 1], tb[SSIM_HALO][SSIM_HALO + 1];
+	__shared__ float hs[5][SSIM_HALO][SSIM_T + 1];
+	__shared__ float red[2][4];
+	const size_t plane = (size_t)blockIdx.z * H * W;
+	const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
+	ssim_load_tile(img1 + plane, img2 + plane, H, W, x0, y0, ta, tb);
+	__syncthreads();
+	// horizontal pass: 26 rows x 16 columns x 5 moments
+	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_T; i += 256) {
+		const int ly = i / SSIM_T, lx = i - ly * SSIM_T;
+		float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+		for (int k = 0; k < 11; k++) {
+			const float w = win.g[k], a = ta[ly][lx + k], b = tb[ly][lx + k];
+			s1 += w * a; s2 += w * b; s11 += w * (a * a); s22 += w * (b * b); s12 += w * (a * b);
+		}
+		hs[0][ly][lx] = s1; hs[1][ly][lx] = s2; hs[2][ly][lx] = s11; hs[3][ly][lx] = s22; hs[4][ly][lx] = s12;
+	}
+	__syncthreads();
+	const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+	const int gx = x0 + tx, gy = y0 + ty;
+	float l1 = 0.f, sv = 0.f;
+	if (gx < W && gy < H) {
+		float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+		for (int k = 0; k < 11; k++) {
+			const float w = win.g[k];
+			mu1 += w * hs[0][ty + k][tx]; mu2 += w * hs[1][ty + k][tx];
+			e11 += w * hs[2][ty + k][tx]; e22 += w * hs[3][ty + k][tx]; e12 += w * hs[4][ty + k][tx];
+		}
+		const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+		const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
+		const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
+		const float inv = 1.0f / (Cc * D);
+		sv = A * B * inv;
+		const size_t o = plane + (size_t)gy * W + gx;
+		l1 = fabsf(ta[ty + SSIM_R][tx + SSIM_R] - tb[ty + SSIM_R][tx + SSIM_R]);
+		if (ssim_map) ssim_map[o] = sv;
+		if (dm_dmu1) {
+			// with mu1, E[x^2], E[xy] as the independent conv outputs of image 1 (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
+			dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * sv * (D - Cc) * inv;
+			dm_dsigma1_sq[o] = -sv / D;
+			dm_dsigma12[o] = 2.f * A * inv;
+		}
+	}
+	// block sums -> one atomic per block and quantity
+	float r[4] = {l1, sv, 0.f, 0.f};
+	wave_sum4(r);
+	const int wave = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 63) { red[0][wave] = r[0]; red[1][wave] = r[1]; }
+	__syncthreads();
+	if (threadIdx.x < 2) atomicAdd(sums + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// Backward: dL/dimg1 = w_l1 * sign(x - y) + w_ssim * [ conv(dm_dmu1) + 2 x conv(dm_dsigma1_sq) + y conv(dm_dsigma12) ]
+// (the window is symmetric, so the adjoint of the zero-padded correlation is the same correlation of the zero-padded planes).
+__global__ void __launch_bounds__(256)
+ssim_l1_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimWindow win,
+                   const float* __restrict__ weights /* [2]: dL/d(sum |x-y|), dL/d(sum ssim) */, const float* __restrict__ dm_dmu1,
+                   const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12, float* __restrict__ dL_dimg1) {
+	__shared__ float t0[SSIM_HALO][SSIM_HALO + 1], t1[SSIM_HALO][SSIM_HALO + 1], t2[SSIM_HALO][SSIM_HALO + 1];
+	__shared__ float hs[3][SSIM_HALO][SSIM_T + 1];
+	const size_t plane = (size_t)blockIdx.z * H * W;
+	const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
+	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_HALO; i += 256) {
+		const int ly = i / SSIM_HALO, lx = i - ly * SSIM_HALO;
+		const int gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
+		const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+		const size_t o = plane + (size_t)gy * W + gx;
+		t0[ly][lx] = in ? dm_dmu1[o] : 0.f;
+		t1[ly][lx] = in ? dm_dsigma1_sq[o] : 0.f;
+		t2[ly][lx] = in ? dm_dsigma12[o] : 0.f;
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_T; i += 256) {
+		const int ly = i / SSIM_T, lx = i - ly * SSIM_T;
+		float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+		for (int k = 0; k < 11; k++) {
+			const float w = win.g[k];
+			s0 += w * t0[ly][lx + k]; s1 += w * t1[ly][lx + k]; s2 += w * t2[ly][lx + k];
+		}
+		hs[0][ly][lx] = s0; hs[1][ly][lx] = s1; hs[2][ly][lx] = s2;
+	}
+	__syncthreads();
+	const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+	const int gx = x0 + tx, gy = y0 + ty;
+	if (gx >= W || gy >= H) return;
+	float c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+	for (int k = 0; k < 11; k++) {
+		const float w = win.g[k];
+		c0 += w * hs[0][ty + k][tx]; c1 += w * hs[1][ty + k][tx]; c2 += w * hs[2][ty + k][tx];
+	}
+	const size_t o = plane + (size_t)gy * W + gx;
+	const float x = img1[o], y = img2[o];
+	const float d = x - y;
+	const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // torch.abs backward: sign(), 0 at 0
+	dL_dimg1[o] = weights[0] * sgn + weights[1] * (c0 + 2.f * x * c1 + y * c2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, amsgrad = False, weight_decay = 0, maximize = False; torch/optim/adam.py _single_tensor_adam):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#define ADAM_MAX_SEG 16
+struct AdamSegs {
+	int n;
+	unsigned long long end[ADAM_MAX_SEG];   // exclusive end offset of segment i (begin = end[i-1])
+	float lr[ADAM_MAX_SEG], lr2[ADAM_MAX_SEG];
+	unsigned int period[ADAM_MAX_SEG], split[ADAM_MAX_SEG];
+};
+__device__ __forceinline__ float adam_lr(const AdamSegs& s, unsigned long long i) {
+	int k = 0;
+	while (k + 1 < s.n && i >= s.end[k]) k++;
+	const unsigned long long begin = k ? s.end[k - 1] : 0ull;
+	if (s.period[k] == 0u) return s.lr[k];
+	return ((i - begin) % s.period[k]) < s.split[k] ? s.lr[k] : s.lr2[k];
+}
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float bc1,
+                                         float sqrt_bc2) {
+	m = b1 * m + (1.f - b1) * g;
+	v = b2 * v + (1.f - b2) * (g * g);
+	const float denom = sqrtf(v) / sqrt_bc2 + eps;
+	p -= (lr / bc1) * (m / denom);
+}
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+            unsigned long long n, AdamSegs segs, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2) {
+	// (inv_bc1, inv_sqrt_bc2 carry bc1 and sqrt(bc2) themselves: the divisions stay in the kernel, as in torch's addcdiv path)
+	const unsigned long long i4 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4ull;
+	if (i4 >= n) return;
+	if (i4 + 4 <= n) {
+		float4 p = *reinterpret_cast<float4*>(param + i4);
+		const float4 g = *reinterpret_cast<const float4*>(grad + i4);
+		float4 m = *reinterpret_cast<float4*>(exp_avg + i4), v = *reinterpret_cast<float4*>(exp_avg_sq + i4);
+		adam_one(p.x, g.x, m.x, v.x, adam_lr(segs, i4), b1, b2, eps, inv_bc1, inv_sqrt_bc2);
+		adam_one(p.y, g.y, m.y, v.y, adam_lr(segs, i4 + 1), b1, b2, eps, inv_bc1, inv_sqrt_bc2);
+		adam_one(p.z, g.z, m.z, v.z, adam_lr(segs, i4 + 2), b1, b2, eps, inv_bc1, inv_sqrt_bc2);
+		adam_one(p.w, g.w, m.w, v.w, adam_lr(segs, i4 + 3), b1, b2, eps, inv_bc1, inv_sqrt_bc2);
+		*reinterpret_cast<float4*>(param + i4) = p;
+		*reinterpret_cast<float4*>(exp_avg + i4) = m;
+		*reinterpret_cast<float4*>(exp_avg_sq + i4) = v;
+	} else {
+		for (unsigned long long i = i4; i < n; i++) {
+			float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+			adam_one(p, grad[i], m, v, adam_lr(segs, i), b1, b2, eps, inv_bc1, inv_sqrt_bc2);
+			param[i] = p; exp_avg[i] = m; exp_avg_sq[i] = v;
+		}
+	}
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, int H, int W, float C1, float C2, float* sums, float* ssim_map,
+                                   float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (C < 0 || H < 0 || W < 0 || !sums) { set_error("gsr_ssim_l1_forward: invalid argument"); return GSR_E_INVALID; }
+	GSR_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream));
+	if (C == 0 || H == 0 || W == 0) return 0;
+	if (!img1 || !img2 || ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr)) || ((dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr))) {
+		set_error("gsr_ssim_l1_forward: NULL image or partial set of derivative planes");
+		return GSR_E_INVALID;
+	}
+	static const SsimWindow win = make_window();
+	dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C);
+	{
+		StageTimer st_(GSR_STAGE_LOSS_FWD, stream);
+		ssim_l1_fwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, H, W, win, C1, C2, sums, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+	}
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_ssim_l1_backward(const float* img1, const float* img2, int C, int H, int W, const float* weights, const float* dm_dmu1,
+                                    const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (C < 0 || H < 0 || W < 0) { set_error("gsr_ssim_l1_backward: invalid argument"); return GSR_E_INVALID; }
+	if (C == 0 || H == 0 || W == 0) return 0;
+	if (!img1 || !img2 || !weights || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1) {
+		set_error("gsr_ssim_l1_backward: NULL argument");
+		return GSR_E_INVALID;
+	}
+	static const SsimWindow win = make_window();
+	dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C);
+	{
+		StageTimer st_(GSR_STAGE_LOSS_BWD, stream);
+		ssim_l1_bwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, H, W, win, weights, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1);
+	}
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, const gsr_adam_segment* segments,
+                             int num_segments, float beta1, float beta2, float eps, int step, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (n == 0) return 0;
+	if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || num_segments < 1 || num_segments > ADAM_MAX_SEG || step < 1) {
+		set_error("gsr_adam_step: invalid argument (NULL buffer, step < 1 or more than 16 segments)");
+		return GSR_E_INVALID;
+	}
+	if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) != 0) {
+		set_error("gsr_adam_step: buffers must be 16-byte aligned");
+		return GSR_E_INVALID;
+	}
+	AdamSegs s;
+	memset(&s, 0, sizeof(s));
+	s.n = num_segments;
+	uint64_t prev = 0;
+	for (int i = 0; i < num_segments; i++) {
+		if (segments[i].begin != prev || segments[i].end < segments[i].begin || (segments[i].period != 0 && segments[i].split > segments[i].period)) {
+			set_error("gsr_adam_step: segments must tile [0, n) in order");
+			return GSR_E_INVALID;
+		}
+		prev = segments[i].end;
+		s.end[i] = segments[i].end; s.lr[i] = segments[i].lr; s.lr2[i] = segments[i].lr2;
+		s.period[i] = segments[i].period; s.split[i] = segments[i].split;
+	}
+	if (prev != n) { set_error("gsr_adam_step: segments must tile [0, n) in order"); return GSR_E_INVALID; }
+	// bias corrections in double on the host, as Python floats are in torch/optim/adam.py
+	const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+	const unsigned long long nvec = (n + 3) / 4;
+	{
+		StageTimer st_(GSR_STAGE_ADAM, stream);
+		adam_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, n, s, beta1, beta2, eps, (float)bc1,
+		                                                               (float)sqrt(bc2));
+	}
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}

@@ -58,6 +58,19 @@ def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_streng
     return rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer, out_refl, gaussian_weights
 
 
+# Optional gradient sink (not in the reference): dict name -> preallocated contiguous float32 tensor for any of
+# means3D (P,3), shs (P,M,3), opacities (P,1), scales (P,2), rotations (P,4), refl_strengths (P,1).  While set, the backward
+# kernels write those gradients directly into the given tensors (e.g. views of one flat all-reduce / optimizer buffer,
+# gsr_dist.FlatGrads) and the autograd Function returns None for the corresponding inputs, so autograd neither
+# allocates nor accumulates them: the sink holds THIS backward's gradient (overwritten, not summed).
+grad_sink = None
+
+
+def set_grad_sink(sink):
+    global grad_sink
+    grad_sink = dict(sink) if sink else None
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, dL_dout_refl_strength_map, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
@@ -72,10 +85,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     dev = means3D.device
     o = dict(dtype=torch.float32, device=dev)
     # the library writes every element, so no zero-fill is needed (the reference uses torch::zeros)
-    mk = torch.empty if P != 0 else torch.zeros
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = mk((P, 3), **o), mk((P, 3), **o), mk((P, NUM_CHANNELS), **o), mk((P, 3), **o)
-    dL_dopacity, dL_dtransMat, dL_dsh = mk((P, 1), **o), mk((P, 9), **o), mk((P, M, 3), **o)
-    dL_dscales, dL_drotations, dL_drefl = mk((P, 2), **o), mk((P, 4), **o), mk((P, 1), **o)
+    mk0 = torch.empty if P != 0 else torch.zeros
+
+    def mk(shape, sink_name=None, **kw):
+        # gradient sink (extension, see set_grad_sink): the kernel writes this output straight into a caller-owned tensor
+        t = grad_sink.get(sink_name) if (grad_sink is not None and sink_name is not None) else None
+        if t is not None:
+            if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise ValueError(f"grad sink '{sink_name}': expected contiguous float32 {tuple(shape)} on {dev}, got {tuple(t.shape)} {t.dtype}")
+            return t
+        return mk0(shape, **kw)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = mk((P, 3), "means3D", **o), mk((P, 3), **o), mk((P, NUM_CHANNELS), **o), mk((P, 3), **o)
+    dL_dopacity, dL_dtransMat, dL_dsh = mk((P, 1), "opacities", **o), mk((P, 9), **o), mk((P, M, 3), "shs", **o)
+    dL_dscales, dL_drotations, dL_drefl = mk((P, 2), "scales", **o), mk((P, 4), "rotations", **o), mk((P, 1), "refl_strengths", **o)
     if dL_dout_refl_strength_map is None or dL_dout_refl_strength_map.numel() == 0:
         dL_dout_refl_strength_map = torch.zeros((1, H, W), **o)
     if P != 0:

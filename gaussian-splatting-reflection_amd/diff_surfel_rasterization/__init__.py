@@ -77,10 +77,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_means2D, grad_colors_precomp, grad_refl_strengths, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
             grad_scales, grad_rotations = grads_
         # autograd insists on None for inputs that were passed as empty placeholders
-        def opt(g, ref):
+        sink = _C.grad_sink or {}
+        def opt(g, ref, name=None):
+            if name is not None and name in sink:
+                return None   # already written into the caller's sink tensor (see _C.set_grad_sink)
             return g if (ref is not None and ref.numel() != 0) else None
-        return (grad_means3D, grad_means2D, opt(grad_sh, sh), opt(grad_colors_precomp, colors_precomp),
-                opt(grad_refl_strengths, refl_strengths), grad_opacities, opt(grad_scales, scales), opt(grad_rotations, rotations),
+        return (opt(grad_means3D, means3D, "means3D"), grad_means2D, opt(grad_sh, sh, "shs"), opt(grad_colors_precomp, colors_precomp),
+                opt(grad_refl_strengths, refl_strengths, "refl_strengths"), (None if "opacities" in sink else grad_opacities),
+                opt(grad_scales, scales, "scales"), opt(grad_rotations, rotations, "rotations"),
                 opt(grad_cov3Ds_precomp, cov3Ds_precomp), None, None)
 
 
@@ -103,6 +107,12 @@ class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+
+    @staticmethod
+    def set_grad_sink(sink):
+        """Extension (not in the reference): route this rasterizer's parameter gradients into preallocated tensors,
+        see _C.set_grad_sink.  Pass None to restore plain autograd behaviour."""
+        _C.set_grad_sink(sink)
 
     def markVisible(self, positions):
         # Mark visible points (based on frustum culling for camera) with a boolean

@@ -39,8 +39,34 @@ class FlatGrads:
             p.grad = self.flat[off:off + n].view(p.shape)
             off += n
 
+    @classmethod
+    def mirroring(cls, flat_params):
+        """Gradient buffer with exactly the layout of a gsr_train.FlatParams (same offsets incl. alignment padding), as
+        the fused Adam kernel requires."""
+        self = cls.__new__(cls)
+        self.params = flat_params.p
+        self.names = list(flat_params.names)
+        self.flat = torch.zeros_like(flat_params.flat)
+        self.slices = dict(flat_params.slices)
+        for k, p in self.params.items():
+            a, b = self.slices[k]
+            p.grad = self.flat[a:b].view(p.shape)
+        return self
+
     def zero_(self):
         self.flat.zero_()
+
+    def sink(self, names=("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths")):
+        """Views of the flat buffer keyed by the rasterizer's gradient names, for GaussianRasterizer.set_grad_sink:
+        the backward kernels then write straight into the all-reduce payload (no zero-fill, no accumulate pass).
+        Valid for ONE backward per step and rank; with several views per step keep plain autograd accumulation."""
+        return {k: self.view(k) for k in names if k in self.slices}
+
+    def zero_except_(self, names):
+        """Zero the slices that are still accumulated by autograd (everything not covered by a sink)."""
+        for k, (a, b) in self.slices.items():
+            if k not in names:
+                self.flat[a:b].zero_()
 
     def view(self, name):
         a, b = self.slices[name]

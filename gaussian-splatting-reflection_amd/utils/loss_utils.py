@@ -1,0 +1,113 @@
+"""Photometric losses of the reference's train loop on the HIP path (reference: utils/loss_utils.py).
+
+Same names and call shapes as the reference module: `l1_loss`, `l2_loss`, `ssim`, `fast_ssim`, `FusedSSIMMap`
+(utils/loss_utils.py:24-97), plus `photometric_loss`, the fused form of train.py:167-173
+`(1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim)` that runs ONE forward and ONE backward kernel.
+All of them call libgsr_hip.so (gsr_ssim_l1_forward / gsr_ssim_l1_backward, include/gsr_hip.h); there is no
+torch-conv fallback.  Only the reference's window (size 11, sigma 1.5, zero padding 5) is implemented.
+"""
+import torch
+
+from _gsr import check, f32c, lib, ptr, require_cuda, stream_ptr
+
+C1 = 0.01 ** 2
+C2 = 0.03 ** 2
+
+
+def _chw(img, name):
+    require_cuda(img, name)
+    if img.dim() == 4:
+        if img.size(0) != 1:
+            raise ValueError(f"{name}: batched input is supported for batch size 1 only, got {tuple(img.shape)}")
+        img = img[0]
+    if img.dim() != 3:
+        raise ValueError(f"{name}: expected (C,H,W) or (1,C,H,W), got {tuple(img.shape)}")
+    return f32c(img, name)
+
+
+class _SsimL1(torch.autograd.Function):
+    """sums = [sum |img1 - img2|, sum ssim_map]; gradient w.r.t. img1 only (the ground truth gets none, as in
+    FusedSSIMMap.backward, utils/loss_utils.py:33-38)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, c1, c2, want_map):
+        x, y = _chw(img1, "img1"), _chw(img2, "img2")
+        if x.shape != y.shape:
+            raise ValueError(f"image shapes differ: {tuple(x.shape)} vs {tuple(y.shape)}")
+        C, H, W = x.shape
+        dev = x.device
+        sums = torch.empty(2, dtype=torch.float32, device=dev)
+        need_grad = img1.requires_grad
+        maps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev) if need_grad else None
+        smap = torch.empty((C, H, W), dtype=torch.float32, device=dev) if want_map else None
+        with torch.cuda.device(dev):
+            check(lib.gsr_ssim_l1_forward(ptr(x), ptr(y), C, H, W, float(c1), float(c2), ptr(sums), ptr(smap),
+                                          ptr(maps[0]) if need_grad else None, ptr(maps[1]) if need_grad else None,
+                                          ptr(maps[2]) if need_grad else None, stream_ptr(dev)), "gsr_ssim_l1_forward")
+        ctx.save_for_backward(x, y, maps)
+        ctx.in_shape = img1.shape
+        ctx.want_map = want_map
+        if want_map:
+            ctx.mark_non_differentiable(smap)
+            return sums, smap
+        return sums, torch.empty(0, device=dev)
+
+    @staticmethod
+    def backward(ctx, g_sums, _):
+        x, y, maps = ctx.saved_tensors
+        C, H, W = x.shape
+        grad = torch.empty_like(x)
+        w = f32c(g_sums, "grad_sums")
+        with torch.cuda.device(x.device):
+            check(lib.gsr_ssim_l1_backward(ptr(x), ptr(y), C, H, W, ptr(w), ptr(maps[0]), ptr(maps[1]), ptr(maps[2]), ptr(grad),
+                                           stream_ptr(x.device)), "gsr_ssim_l1_backward")
+        return grad.view(ctx.in_shape), None, None, None, None
+
+
+def _sums(img1, img2):
+    return _SsimL1.apply(img1, img2, C1, C2, False)[0]
+
+
+def l1_loss(network_output, gt):
+    # utils/loss_utils.py:40-41
+    return _sums(network_output, gt)[0] / network_output.numel()
+
+
+def l2_loss(network_output, gt):
+    # utils/loss_utils.py:43-44 (plain elementwise; not on the train-step path)
+    return ((network_output - gt) ** 2).mean()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    # utils/loss_utils.py:62-97
+    if window_size != 11:
+        raise NotImplementedError("only the reference's 11x11 window is implemented on the HIP path")
+    if not size_average:
+        raise NotImplementedError("size_average=False is not used by the reference's train loop and is not implemented")
+    return _sums(img1, img2)[1] / img1.numel()
+
+
+def fast_ssim(img1, img2):
+    # utils/loss_utils.py:95-97
+    return _sums(img1, img2)[1] / img1.numel()
+
+
+class FusedSSIMMap(torch.autograd.Function):
+    """utils/loss_utils.py:24-38: returns the per-pixel SSIM map; its gradient needs the map's upstream gradient per
+    pixel, which the fused kernels do not take (they differentiate the SUM of the map).  Kept for name parity: forward
+    only."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, img1, img2):
+        return _SsimL1.apply(img1.detach(), img2, c1, c2, True)[1].view(img1.shape)
+
+    @staticmethod
+    def backward(ctx, opt_grad):
+        raise NotImplementedError("per-pixel SSIM-map gradients are not implemented; use ssim()/fast_ssim()/photometric_loss()")
+
+
+def photometric_loss(image, gt_image, lambda_dssim=0.2):
+    """train.py:167-173: (1 - lambda) * L1 + lambda * (1 - SSIM), one fused forward and one fused backward kernel."""
+    s = _sums(image, gt_image)
+    n = image.numel()
+    return (1.0 - lambda_dssim) * (s[0] / n) + lambda_dssim * (1.0 - s[1] / n)

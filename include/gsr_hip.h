@@ -161,6 +161,41 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
 
 
 /* ---------------------------------------------------------------------------------------------
+ * Training-step passes around the rasterizer.
+ *
+ * gsr_ssim_l1_forward / _backward: the photometric loss of the reference's train loop, train.py:167-173
+ *   loss = (1 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1 - ssim(image, gt))
+ * with l1_loss = mean |x - y| (utils/loss_utils.py:40-41) and ssim = mean of the 11x11 Gaussian-window (sigma 1.5,
+ * zero padding 5, per channel) SSIM map (utils/loss_utils.py:62-92).  They also stand in for the optional
+ * fusedssim / fusedssim_backward pair the reference tries to import (utils/loss_utils.py:16-38).
+ *   img1 (rendered), img2 (ground truth): float[C,H,W].
+ *   forward: sums float[2] <- { sum |x - y|, sum ssim_map } (zeroed by the call); optional ssim_map float[C,H,W];
+ *     optional dm_dmu1, dm_dsigma1_sq, dm_dsigma12 float[C,H,W] (all three or none): planes saved for the backward.
+ *   backward: weights float[2] (device) = { dL/d sums[0], dL/d sums[1] };
+ *     dL_dimg1 float[C,H,W] <- weights[0] * sign(x - y) + weights[1] * d(sum ssim)/dx.  img2 gets no gradient. */
+int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, int H, int W, float C1, float C2, float* sums,
+                        float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gsr_ssim_l1_backward(const float* img1, const float* img2, int C, int H, int W, const float* weights,
+                         const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
+                         void* stream);
+
+/* gsr_adam_step: torch.optim.Adam(lr per group, betas, eps, amsgrad=False, weight_decay=0) as the reference sets it up
+ * (scene/gaussian_model.py:196-209: eight groups, eps = 1e-15), fused over ONE flat buffer: param, grad, exp_avg and
+ * exp_avg_sq are float[n], 16-byte aligned, laid out identically.  `segments` (host array, at most 16, tiling [0, n) in
+ * order) give the learning rate of each parameter group; a group whose tensor interleaves two reference groups
+ * (shs = cat(f_dc, f_rest): 3 of every 48 floats use feature_lr, the other 45 feature_lr / 20) sets period/split:
+ * element i of the segment uses lr if ((i - begin) % period) < split else lr2; period 0 = plain lr.
+ * `step` is the 1-based Adam step counter (bias corrections 1 - beta^step are formed in double on the host). */
+typedef struct {
+	uint64_t begin, end;
+	float lr, lr2;
+	uint32_t period, split;
+} gsr_adam_segment;
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                  const gsr_adam_segment* segments, int num_segments, float beta1, float beta2, float eps, int step,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-stage device timing (bench.py's roofline leg).  When enabled, every stage launch is bracketed by
  * hipEvents recorded on the stream the stage runs on; gsr_profile_collect() synchronises those events,
  * adds up elapsed milliseconds and launch counts per stage since the last enable/collect, and resets.
@@ -177,7 +212,10 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
 #define GSR_STAGE_REFL_BWD 9
 #define GSR_STAGE_CUBEMAP_FWD 10
 #define GSR_STAGE_CUBEMAP_BWD 11
-#define GSR_STAGE_COUNT 12
+#define GSR_STAGE_LOSS_FWD 12
+#define GSR_STAGE_LOSS_BWD 13
+#define GSR_STAGE_ADAM 14
+#define GSR_STAGE_COUNT 15
 /* Test/diagnostic switches.  "cull" (default 1): per-wave conservative bounding-box culling inside the tile
  * kernels; outputs are bit-identical with 0 and 1 (it only skips pairs that cannot blend). */
 int gsr_set_option(const char* name, int value);

@@ -21,8 +21,8 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with its Makefile (g++ only, a few seconds)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    # always through make: it is a no-op when the library is newer than every source
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return _LIB_PATH
 
 
@@ -312,3 +312,32 @@ def sh_backward(deg, means, campos, shs, clamped, dL_dcolor, dtype=np.float32):
     ds = np.zeros((N, M, 3), dtype)
     getattr(lib(), f"orc_sh_backward_{_suf(dtype)}")(N, int(deg), M, _p(m), _p(c), _p(s), _p(cl), _p(g), _p(dm), _p(ds))
     return dm, ds
+
+
+def ssim_l1_forward(img1, img2, C1=0.01 ** 2, C2=0.03 ** 2, dtype=np.float32):
+    """utils/loss_utils.py l1_loss + _ssim pieces: returns (sum |x-y|, sum ssim_map, ssim_map [C,H,W])."""
+    a, b = _arr(img1, dtype), _arr(img2, dtype)
+    C, H, W = a.shape
+    sums = np.zeros(2, dtype)
+    smap = np.zeros((C, H, W), dtype)
+    r = _real(dtype)
+    getattr(lib(), f"orc_ssim_l1_forward_{_suf(dtype)}")(_p(a), _p(b), C, H, W, r(C1), r(C2), _p(sums), _p(smap))
+    return float(sums[0]), float(sums[1]), smap
+
+
+def ssim_l1_backward(img1, img2, w_l1, w_ssim, C1=0.01 ** 2, C2=0.03 ** 2, dtype=np.float32):
+    """d(w_l1 * sum|x-y| + w_ssim * sum ssim_map) / d img1, [C,H,W]."""
+    a, b = _arr(img1, dtype), _arr(img2, dtype)
+    C, H, W = a.shape
+    d = np.zeros((C, H, W), dtype)
+    r = _real(dtype)
+    getattr(lib(), f"orc_ssim_l1_backward_{_suf(dtype)}")(_p(a), _p(b), C, H, W, r(C1), r(C2), r(w_l1), r(w_ssim), _p(d))
+    return d
+
+
+def adam(param, grad, exp_avg, exp_avg_sq, lr_per_elem, beta1=0.9, beta2=0.999, eps=1e-15, step=1, dtype=np.float32):
+    """torch.optim.Adam single step (no amsgrad / weight decay); returns updated (param, exp_avg, exp_avg_sq)."""
+    p, g, m, v, lr = (np.array(_arr(x, dtype).reshape(-1), copy=True) for x in (param, grad, exp_avg, exp_avg_sq, lr_per_elem))
+    getattr(lib(), f"orc_adam_{_suf(dtype)}")(_p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.size), _p(lr), ctypes.c_double(beta1),
+                                             ctypes.c_double(beta2), ctypes.c_double(eps), int(step))
+    return p, m, v

@@ -180,3 +180,31 @@ def test_max_tile_id_bits_and_large_splats():
     np.testing.assert_array_equal(hip.state("ranges").astype(np.uint32), o.state("ranges"))
     assert int(o.state("keys").max() >> np.uint64(32)) == 120 * 68 - 1
     assert psnr(hip.out()["color"], ref["color"]) >= 50
+
+
+def test_grad_sink_routes_gradients_into_caller_buffers():
+    """Extension: with a gradient sink set, the backward writes the parameter gradients into the caller's tensors
+    (views of one flat buffer) and autograd leaves the leaves' .grad alone; values equal the plain autograd path."""
+    from diff_surfel_rasterization import GaussianRasterizer
+    from gsr_dist import FlatGrads
+    kw, _, _ = scene_kwargs("S", 4000, 192, 128, 77, -2.8, 3, (0, 0, 0))
+    g = S.make_upstream_grads(128, 192, 5)
+    plain = HipSurfel(kw).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    hip = HipSurfel(kw)
+    params = dict(means3D=hip.means3D, shs=hip.shs, opacities=hip.opac, scales=hip.scales, rotations=hip.rots, refl_strengths=hip.refl)
+    fg = FlatGrads(params)
+    fg.flat.fill_(float("nan"))          # every element must be overwritten by the kernels
+    before = {k: p.grad.data_ptr() for k, p in params.items()}
+    GaussianRasterizer.set_grad_sink(fg.sink())
+    try:
+        hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    finally:
+        GaussianRasterizer.set_grad_sink(None)
+    names = dict(means3D="dL_dmeans3D", shs="dL_dsh", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations",
+                 refl_strengths="dL_drefl_strengths")
+    for k, p in params.items():
+        assert p.grad.data_ptr() == before[k]                      # still the flat-buffer view
+        got = fg.view(k).cpu().numpy()
+        assert np.isfinite(got).all(), k
+        ref = plain[names[k]].reshape(got.shape)
+        assert rel_maxnorm(got, ref) <= 5e-5, k                    # atomics order differs run to run
