@@ -49,7 +49,7 @@ __device__ __forceinline__ void ssim_load_tile(const float* __restrict__ a, cons
 // optionally the SSIM map and the three planes d ssim / d mu1, d ssim / d E[x^2], d ssim / d E[xy] for the backward.
 __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimWindow win, float C1, float C2,
-                   float* __restrict__ sums, float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
+                   float* __restrict__ partials, float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
                    float* __restrict__ dm_dsigma12) {
 	__shared__ float ta[SSIM_HALO][SSIM_HALO + 1], tb[SSIM_HALO][SSIM_HALO + 1];
 	__shared__ float hs[5][SSIM_HALO][SSIM_T + 1];
@@ -96,13 +96,31 @@ ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img
 			dm_dsigma12[o] = 2.f * A * inv;
 		}
 	}
-	// block sums -> one atomic per block and quantity
+	// block sums -> one partial pair per block (24 k blocks adding into ONE address serialise at the memory side: measured
+	// 0.32 ms for the 1080p loss with atomics); ssim_l1_reduce_kernel adds them up in a fixed order
 	float r[4] = {l1, sv, 0.f, 0.f};
 	wave_sum4(r);
 	const int wave = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 63) { red[0][wave] = r[0]; red[1][wave] = r[1]; }
 	__syncthreads();
-	if (threadIdx.x < 2) atomicAdd(sums + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+	if (threadIdx.x < 2) {
+		const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+		partials[2 * blk + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+	}
+}
+
+// second stage: one workgroup, double accumulation, fixed order -> the loss value is bitwise reproducible
+__global__ void __launch_bounds__(256) ssim_l1_reduce_kernel(const float* __restrict__ partials, size_t nblocks, float* __restrict__ sums) {
+	__shared__ double red[2][256];
+	double a = 0.0, b = 0.0;
+	for (size_t i = threadIdx.x; i < nblocks; i += 256) { a += (double)partials[2 * i]; b += (double)partials[2 * i + 1]; }
+	red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+	__syncthreads();
+	for (int s = 128; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { sums[0] = (float)red[0][0]; sums[1] = (float)red[1][0]; }
 }
 
 // Backward: dL/dimg1 = w_l1 * sign(x - y) + w_ssim * [ conv(dm_dmu1) + 2 x conv(dm_dsigma1_sq) + y conv(dm_dsigma12) ]
@@ -206,12 +224,17 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 
 using namespace gsr;
 
-extern "C" int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, int H, int W, float C1, float C2, float* sums, float* ssim_map,
-                                   float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream_) {
+extern "C" size_t gsr_ssim_l1_scratch_floats(int C, int H, int W) {
+	if (C <= 0 || H <= 0 || W <= 0) return 0;
+	return 2 * (size_t)C * ((H + SSIM_T - 1) / SSIM_T) * ((W + SSIM_T - 1) / SSIM_T);
+}
+
+extern "C" int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, int H, int W, float C1, float C2, float* sums, float* scratch,
+                                   float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (C < 0 || H < 0 || W < 0 || !sums) { set_error("gsr_ssim_l1_forward: invalid argument"); return GSR_E_INVALID; }
-	GSR_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream));
-	if (C == 0 || H == 0 || W == 0) return 0;
+	if (C == 0 || H == 0 || W == 0) { GSR_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(float), stream)); return 0; }
+	if (!scratch) { set_error("gsr_ssim_l1_forward: scratch of gsr_ssim_l1_scratch_floats(C,H,W) floats is required"); return GSR_E_INVALID; }
 	if (!img1 || !img2 || ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr)) || ((dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr))) {
 		set_error("gsr_ssim_l1_forward: NULL image or partial set of derivative planes");
 		return GSR_E_INVALID;
@@ -220,7 +243,8 @@ extern "C" int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, 
 	dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, C);
 	{
 		StageTimer st_(GSR_STAGE_LOSS_FWD, stream);
-		ssim_l1_fwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, H, W, win, C1, C2, sums, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+		ssim_l1_fwd_kernel<<<grid, 256, 0, stream>>>(img1, img2, H, W, win, C1, C2, scratch, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12);
+		ssim_l1_reduce_kernel<<<1, 256, 0, stream>>>(scratch, (size_t)grid.x * grid.y * grid.z, sums);
 	}
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;

@@ -40,8 +40,9 @@ class _SsimL1(torch.autograd.Function):
         need_grad = img1.requires_grad
         maps = torch.empty((3, C, H, W), dtype=torch.float32, device=dev) if need_grad else None
         smap = torch.empty((C, H, W), dtype=torch.float32, device=dev) if want_map else None
+        scratch = torch.empty(max(1, int(lib.gsr_ssim_l1_scratch_floats(C, H, W))), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            check(lib.gsr_ssim_l1_forward(ptr(x), ptr(y), C, H, W, float(c1), float(c2), ptr(sums), ptr(smap),
+            check(lib.gsr_ssim_l1_forward(ptr(x), ptr(y), C, H, W, float(c1), float(c2), ptr(sums), ptr(scratch), ptr(smap),
                                           ptr(maps[0]) if need_grad else None, ptr(maps[1]) if need_grad else None,
                                           ptr(maps[2]) if need_grad else None, stream_ptr(dev)), "gsr_ssim_l1_forward")
         ctx.save_for_backward(x, y, maps)

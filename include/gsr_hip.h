@@ -169,12 +169,15 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
  * zero padding 5, per channel) SSIM map (utils/loss_utils.py:62-92).  They also stand in for the optional
  * fusedssim / fusedssim_backward pair the reference tries to import (utils/loss_utils.py:16-38).
  *   img1 (rendered), img2 (ground truth): float[C,H,W].
- *   forward: sums float[2] <- { sum |x - y|, sum ssim_map } (zeroed by the call); optional ssim_map float[C,H,W];
+ *   forward: sums float[2] <- { sum |x - y|, sum ssim_map }; scratch float[gsr_ssim_l1_scratch_floats(C,H,W)] (per-block
+ *     partial sums, added up in a fixed order: the loss value is bitwise reproducible); optional ssim_map float[C,H,W];
  *     optional dm_dmu1, dm_dsigma1_sq, dm_dsigma12 float[C,H,W] (all three or none): planes saved for the backward.
  *   backward: weights float[2] (device) = { dL/d sums[0], dL/d sums[1] };
  *     dL_dimg1 float[C,H,W] <- weights[0] * sign(x - y) + weights[1] * d(sum ssim)/dx.  img2 gets no gradient. */
+size_t gsr_ssim_l1_scratch_floats(int C, int H, int W);
 int gsr_ssim_l1_forward(const float* img1, const float* img2, int C, int H, int W, float C1, float C2, float* sums,
-                        float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+                        float* scratch, float* ssim_map, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                        void* stream);
 int gsr_ssim_l1_backward(const float* img1, const float* img2, int C, int H, int W, const float* weights,
                          const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                          void* stream);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _protos():
     src = open(os.path.join(ROOT, "include", "gsr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return re.findall(r"(?:int|const char\*)\s+(gsr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    return re.findall(r"(?:int|size_t|const char\*)\s+(gsr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
 
 
 def test_library_loads_and_exports_every_declared_symbol(hip_lib_built):
