@@ -2,8 +2,12 @@
 optimizer step, computed with PLAIN TORCH CPU OPS — the reference's loss code is exactly these calls
 (utils/loss_utils.py:40-41, 46-92: gaussian(), create_window(), F.conv2d(padding=5, groups=C); train.py:167-173) and its
 optimizer is torch.optim.Adam(lr=0.0, eps=1e-15) with per-group learning rates (scene/gaussian_model.py:196-209).
-Nothing is imported from the reference.  Run:  python tests/golden/make_train_golden.py
+The reference's own `utils.loss_utils.l1_loss` / `ssim` ARE importable on CPU in the build container,
+so when /root/reference is present they are imported and evaluated on the same float32 inputs; their values are stored
+as `*_ref_l1`, `*_ref_ssim`, `*_ref_grad` (float32 evaluation, as the reference runs) next to the float64 ones.
+Run in the build container:  python tests/golden/make_train_golden.py
 """
+import sys
 import os
 from math import exp
 
@@ -31,9 +35,23 @@ def ssim_map(img1, img2):
     return ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
 
 
+def reference_loss_utils():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        return None
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ref)
+    try:
+        from utils import loss_utils     # the reference's module (imports torch only; its fusedssim import is guarded)
+        return loss_utils
+    finally:
+        sys.path.remove(ref)
+
+
 def main():
     torch.manual_seed(7)
     out = {}
+    ref_lu = reference_loss_utils()
     for tag, (C, H, W) in dict(a=(3, 37, 53), b=(1, 16, 16), c=(3, 9, 70)).items():
         gt = torch.rand(C, H, W, dtype=torch.float64)
         # a blurred + noisy version of gt: realistic SSIM range instead of ~0
@@ -48,6 +66,13 @@ def main():
         out[f"{tag}_ssim_map"] = m.detach().numpy()
         out[f"{tag}_l1"], out[f"{tag}_ssim"], out[f"{tag}_loss"] = l1.item(), m.mean().item(), loss.item()
         out[f"{tag}_grad"] = img.grad.numpy()
+        if ref_lu is not None:
+            x32 = torch.from_numpy(out[f"{tag}_img"]).requires_grad_(True)
+            g32 = torch.from_numpy(out[f"{tag}_gt"])
+            r_l1, r_ss = ref_lu.l1_loss(x32, g32), ref_lu.ssim(x32, g32)
+            (0.8 * r_l1 + 0.2 * (1.0 - r_ss)).backward()
+            out[f"{tag}_ref_l1"], out[f"{tag}_ref_ssim"], out[f"{tag}_ref_grad"] = r_l1.item(), r_ss.item(), x32.grad.numpy()
+            assert abs(r_l1.item() - l1.item()) < 1e-6 and abs(r_ss.item() - m.mean().item()) < 1e-5
         # float32 inputs were rounded from the float64 ones; expected values are for the float64 inputs (difference ~1e-8)
     # Adam: 3 steps on 2 groups with different lrs, float32 like the reference's parameters
     p1, p2 = torch.randn(257, dtype=torch.float32), torch.randn(96, dtype=torch.float32)

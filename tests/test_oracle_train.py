@@ -23,6 +23,10 @@ def test_ssim_l1_oracle_matches_torch_golden(tag):
     d = orc.ssim_l1_backward(img, gt, 0.8 / n, -0.2 / n, dtype=np.float64)
     ref = G[f"{tag}_grad"]
     assert np.abs(d - ref).max() <= 2e-5 * np.abs(ref).max()
+    # values produced by the reference's own utils/loss_utils.py (imported when the fixture was generated), float32
+    assert abs(s_l1 / n - float(G[f"{tag}_ref_l1"])) < 1e-6 and abs(s_ss / n - float(G[f"{tag}_ref_ssim"])) < 1e-5
+    rg = G[f"{tag}_ref_grad"]
+    assert np.abs(d - rg).max() <= 2e-4 * np.abs(rg).max()
     # float32 instantiation (what the GPU tests compare against) stays close to the float64 one
     d32 = orc.ssim_l1_backward(img, gt, 0.8 / n, -0.2 / n, dtype=np.float32)
     assert np.abs(d32 - ref).max() <= 2e-4 * np.abs(ref).max()
