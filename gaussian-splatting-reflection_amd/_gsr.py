@@ -68,6 +68,10 @@ def _load():
     lib.gsr_ssim_l1_forward.argtypes = [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]
     lib.gsr_ssim_l1_backward.restype = c_int
     lib.gsr_ssim_l1_backward.argtypes = [P, P, c_int, c_int, c_int, P, P, P, P, P, P]
+    lib.gsr_surface_forward.restype = c_int
+    lib.gsr_surface_forward.argtypes = [P, P, c_float, c_int, c_int, P, P, P]
+    lib.gsr_surface_backward.restype = c_int
+    lib.gsr_surface_backward.argtypes = [P, P, c_float, c_int, c_int, P, P, P, P, P]
     lib.gsr_adam_step.restype = c_int
     lib.gsr_adam_step.argtypes = [P, P, P, P, ctypes.c_uint64, ctypes.POINTER(AdamSegment), c_int, c_float, c_float, c_float, c_int, P]
     lib.gsr_set_option.restype = c_int
@@ -83,11 +87,11 @@ lib = _load()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_profile_enable",
+            "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",
-          "refl_bwd", "cubemap_fwd", "cubemap_bwd", "loss_fwd", "loss_bwd", "adam"]
+          "refl_bwd", "cubemap_fwd", "cubemap_bwd", "loss_fwd", "loss_bwd", "adam", "surface_fwd", "surface_bwd"]
 
 
 def set_option(name, value):

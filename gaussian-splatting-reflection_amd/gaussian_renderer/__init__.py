@@ -130,6 +130,63 @@ def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, wor
                                      env_map.params['Cubemap_failv'], cam)
 
 
+def _ray_block(view):
+    """Device float[12] for gsr_surface_*: rays_d(x, y) = (x, y, 1) @ M (M = intrins^-1.T @ c2w[:3,:3].T, nine floats
+    row-major) and rays_o, built with the same tensor ops as utils/point_utils.py:9-23 and cached per camera."""
+    wvt, fpt = view.world_view_transform, view.full_proj_transform
+    W, H = int(view.image_width), int(view.image_height)
+    key = ("ray", wvt.data_ptr(), wvt._version, fpt.data_ptr(), fpt._version, W, H)
+    hit = _cam_cache.get(key)
+    if hit is not None:
+        return hit
+    dev = wvt.device
+    c2w = (wvt.T).inverse()
+    ndc2pix = torch.tensor([[W / 2, 0, 0, (W) / 2], [0, H / 2, 0, (H) / 2], [0, 0, 0, 1]]).float().to(dev).T
+    intrins = ((c2w.T @ fpt) @ ndc2pix)[:3, :3].T
+    M = intrins.inverse().T @ c2w[:3, :3].T
+    blk = torch.cat([M.reshape(-1), c2w[:3, 3].reshape(-1)]).float().contiguous()
+    if len(_cam_cache) > 256:
+        _cam_cache.clear()
+    _cam_cache[key] = blk
+    return blk
+
+
+class _SurfacePass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, allmap, raymat, depth_ratio):
+        am = allmap.float().contiguous()
+        if am.dim() != 3 or am.shape[0] != 8:
+            raise RuntimeError("surface_pass: allmap must be (8,H,W)")
+        H, W = am.shape[1], am.shape[2]
+        sd = torch.empty((1, H, W), dtype=torch.float32, device=am.device)
+        sn = torch.empty((3, H, W), dtype=torch.float32, device=am.device)
+        with torch.cuda.device(am.device):
+            check(lib.gsr_surface_forward(ptr(am), ptr(raymat), float(depth_ratio), H, W, ptr(sd), ptr(sn), stream_ptr(am.device)),
+                  "gsr_surface_forward")
+        ctx.save_for_backward(am, raymat, sd)
+        ctx.depth_ratio = float(depth_ratio)
+        return sd, sn
+
+    @staticmethod
+    def backward(ctx, g_sd, g_sn):
+        am, raymat, sd = ctx.saved_tensors
+        H, W = am.shape[1], am.shape[2]
+        g_am = torch.empty_like(am)
+        g_sd = None if g_sd is None else g_sd.float().contiguous()
+        g_sn = None if g_sn is None else g_sn.float().contiguous()
+        with torch.cuda.device(am.device):
+            check(lib.gsr_surface_backward(ptr(am), ptr(raymat), ctx.depth_ratio, H, W, ptr(sd), ptr(g_sd), ptr(g_sn), ptr(g_am),
+                                           stream_ptr(am.device)), "gsr_surface_backward")
+        return g_am, None, None
+
+
+def surface_pass(allmap, view, depth_ratio):
+    """Fused form of gaussian_renderer/__init__.py:151-176 of the reference: returns (surf_depth[1,H,W],
+    surf_normal[3,H,W]) = (expected/median depth blend, depth_to_normal(surf_depth) * alpha.detach()) from the
+    rasterizer's allmap in one kernel; gradients flow to allmap[0], allmap[1] and allmap[5]."""
+    return _SurfacePass.apply(allmap, _ray_block(view), depth_ratio)
+
+
 def depths_to_points(view, depthmap):
     """utils/point_utils.py:9-24"""
     dev = depthmap.device
@@ -213,9 +270,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     render_depth_expected = torch.nan_to_num(render_depth_expected, 0, 0)
     render_dist = allmap[6:7]
     mask = allmap[7:8]
-    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + (pipe.depth_ratio) * render_depth_median
-    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-    surf_normal = surf_normal * (render_alpha).detach()
+    if getattr(pipe, "fused_surface", True):
+        surf_depth, surf_normal = surface_pass(allmap, viewpoint_camera, pipe.depth_ratio)
+    else:   # the reference's op chain (:151-176), kept for comparison
+        surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + (pipe.depth_ratio) * render_depth_median
+        surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
+        surf_normal = surf_normal * (render_alpha).detach()
 
     fused = getattr(pipe, "fused_reflection", True) and not initial_stage
     if fused:

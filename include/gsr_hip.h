@@ -182,6 +182,22 @@ int gsr_ssim_l1_backward(const float* img1, const float* img2, int C, int H, int
                          const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                          void* stream);
 
+/* gsr_surface_forward / _backward: the per-pixel chain render() runs after the rasterizer,
+ * gaussian_renderer/__init__.py:151-176 + utils/point_utils.py:9-37 (depths_to_points, depth_to_normal):
+ *   surf_depth  = nan_to_num(allmap[0] / clamp(allmap[1], 1e-3)) * (1 - depth_ratio) + depth_ratio * nan_to_num(allmap[5])
+ *   surf_normal = normalize(cross(P[y+1] - P[y-1], P[x+1] - P[x-1])) * allmap[1].detach(), P = surf_depth * rays_d + rays_o,
+ *                 zero on the one-pixel border.
+ *   allmap float[8,H,W] (the rasterizer's out_others); raymat DEVICE float[12]: rays_d(x,y) = (x, y, 1) . M with M the
+ *   first nine floats row-major (= intrins^-1.T @ c2w[:3,:3].T of depths_to_points), then rays_o[3];
+ *   surf_depth float[H,W], surf_normal float[3,H,W].
+ *   backward: surf_depth = the forward's output; g_surf_depth float[H,W] and g_surf_normal float[3,H,W] may each be NULL
+ *   (= zero); g_allmap float[8,H,W] is fully written (planes 0, 1, 5 carry gradient, the rest zeros). */
+int gsr_surface_forward(const float* allmap, const float* raymat, float depth_ratio, int H, int W, float* surf_depth,
+                        float* surf_normal, void* stream);
+int gsr_surface_backward(const float* allmap, const float* raymat, float depth_ratio, int H, int W,
+                         const float* surf_depth, const float* g_surf_depth, const float* g_surf_normal, float* g_allmap,
+                         void* stream);
+
 /* gsr_adam_step: torch.optim.Adam(lr per group, betas, eps, amsgrad=False, weight_decay=0) as the reference sets it up
  * (scene/gaussian_model.py:196-209: eight groups, eps = 1e-15), fused over ONE flat buffer: param, grad, exp_avg and
  * exp_avg_sq are float[n], 16-byte aligned, laid out identically.  `segments` (host array, at most 16, tiling [0, n) in
@@ -218,7 +234,9 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 #define GSR_STAGE_LOSS_FWD 12
 #define GSR_STAGE_LOSS_BWD 13
 #define GSR_STAGE_ADAM 14
-#define GSR_STAGE_COUNT 15
+#define GSR_STAGE_SURFACE_FWD 15
+#define GSR_STAGE_SURFACE_BWD 16
+#define GSR_STAGE_COUNT 17
 /* Test/diagnostic switches.  "cull" (default 1): per-wave conservative bounding-box culling inside the tile
  * kernels; outputs are bit-identical with 0 and 1 (it only skips pairs that cannot blend). */
 int gsr_set_option(const char* name, int value);

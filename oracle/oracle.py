@@ -341,3 +341,16 @@ def adam(param, grad, exp_avg, exp_avg_sq, lr_per_elem, beta1=0.9, beta2=0.999, 
     getattr(lib(), f"orc_adam_{_suf(dtype)}")(_p(p), _p(g), _p(m), _p(v), ctypes.c_uint64(p.size), _p(lr), ctypes.c_double(beta1),
                                              ctypes.c_double(beta2), ctypes.c_double(eps), int(step))
     return p, m, v
+
+
+def surface_pass(allmap, raymat, depth_ratio, g_surf_depth=None, g_surf_normal=None, dtype=np.float32):
+    """render()'s depth select + depth_to_normal (gaussian_renderer/__init__.py:151-176, utils/point_utils.py:9-37).
+    Returns (surf_depth [H,W], surf_normal [3,H,W], g_allmap [8,H,W] or None when no cotangent is given)."""
+    am, ray = _arr(allmap, dtype), _arr(raymat, dtype)
+    H, W = am.shape[1], am.shape[2]
+    sd, sn = np.zeros((H, W), dtype), np.zeros((3, H, W), dtype)
+    want = g_surf_depth is not None or g_surf_normal is not None
+    gsd, gsn = _arr(g_surf_depth, dtype), _arr(g_surf_normal, dtype)
+    gam = np.zeros((8, H, W), dtype) if want else None
+    getattr(lib(), f"orc_surface_{_suf(dtype)}")(_p(am), _p(ray), _real(dtype)(depth_ratio), H, W, _p(sd), _p(sn), _p(gsd), _p(gsn), _p(gam))
+    return sd, sn, gam
