@@ -23,6 +23,11 @@ class GsrError(RuntimeError):
     pass
 
 
+class GatherGroup(ctypes.Structure):
+    """gsr_gather_group of include/gsr_hip.h."""
+    _fields_ = [("src_offset", ctypes.c_uint64), ("dst_offset", ctypes.c_uint64), ("width", c_uint32)]
+
+
 class AdamSegment(ctypes.Structure):
     """gsr_adam_segment of include/gsr_hip.h."""
     _fields_ = [("begin", ctypes.c_uint64), ("end", ctypes.c_uint64), ("lr", c_float), ("lr2", c_float), ("period", c_uint32),
@@ -72,6 +77,12 @@ def _load():
     lib.gsr_surface_forward.argtypes = [P, P, c_float, c_int, c_int, P, P, P]
     lib.gsr_surface_backward.restype = c_int
     lib.gsr_surface_backward.argtypes = [P, P, c_float, c_int, c_int, P, P, P, P, P]
+    lib.gsr_densification_stats.restype = c_int
+    lib.gsr_densification_stats.argtypes = [c_int, P, P, P, P, P, P, P, P, P]
+    lib.gsr_gather_rows.restype = c_int
+    lib.gsr_gather_rows.argtypes = [P, P, P, ctypes.c_uint64, ctypes.POINTER(GatherGroup), c_int, P]
+    lib.gsr_split_children.restype = c_int
+    lib.gsr_split_children.argtypes = [c_int, c_int, c_int, P, P, P, P, P, P, P, P]
     lib.gsr_adam_step.restype = c_int
     lib.gsr_adam_step.argtypes = [P, P, P, P, ctypes.c_uint64, ctypes.POINTER(AdamSegment), c_int, c_float, c_float, c_float, c_int, P]
     lib.gsr_set_option.restype = c_int
@@ -87,7 +98,7 @@ lib = _load()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
+            "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libgsr_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
-SOURCES = ["gsr_common.hip", "gsr_gauss.hip", "gsr_surfel.hip", "gsr_cubemap.hip", "gsr_train.hip", "gsr_surface.hip"]
+SOURCES = ["gsr_common.hip", "gsr_gauss.hip", "gsr_surfel.hip", "gsr_cubemap.hip", "gsr_train.hip", "gsr_surface.hip", "gsr_densify.hip"]
 HEADERS = ["gsr_internal.hpp", "gsr_math.hpp", os.path.join("..", "..", "include", "gsr_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; stated because parity of the integer outputs

@@ -42,21 +42,27 @@ class FlatParams:
     """Leaf tensors that are views of one flat float32 buffer (order of `tensors` = order in the buffer; every slice
     starts on a 16-byte boundary so the fused Adam kernel can use float4 accesses across group borders)."""
 
-    def __init__(self, tensors, device):
-        self.names = list(tensors.keys())
-        self.shapes = {k: tuple(v.shape) for k, v in tensors.items()}
+    def __init__(self, tensors, device, shapes=None):
+        """tensors: dict name -> initial value; or None with `shapes` (dict name -> shape) for an uninitialised store."""
+        if tensors is not None:
+            shapes = {k: tuple(v.shape) for k, v in tensors.items()}
+        self.names = list(shapes.keys())
+        self.shapes = {k: tuple(v) for k, v in shapes.items()}
         self.slices = {}
         off = 0
-        for k, v in tensors.items():
-            n = v.numel()
+        for k in self.names:
+            n = 1
+            for d in self.shapes[k]:
+                n *= int(d)
             self.slices[k] = (off, off + n)
             off += (n + 3) // 4 * 4
         self.total = off
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.p = {}
-        for k, v in tensors.items():
+        for k in self.names:
             a, b = self.slices[k]
-            self.flat[a:b].copy_(v.reshape(-1).to(device=device, dtype=torch.float32))
+            if tensors is not None:
+                self.flat[a:b].copy_(tensors[k].reshape(-1).to(device=device, dtype=torch.float32))
             self.p[k] = self.flat[a:b].view(self.shapes[k]).requires_grad_(True)
 
     def like(self):
@@ -109,10 +115,11 @@ class GaussianTrainState:
 
     ORDER = ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths", "cubemap", "fail")
 
-    def __init__(self, tensors, device, spatial_lr_scale=1.0, lrs=None):
+    def __init__(self, tensors, device, spatial_lr_scale=1.0, lrs=None, _params=None):
         lr = dict(DEFAULT_LRS)
         lr.update(lrs or {})
-        self.params = FlatParams({k: tensors[k] for k in self.ORDER if k in tensors}, device)
+        self.lrs, self.spatial_lr_scale = lr, spatial_lr_scale
+        self.params = _params if _params is not None else FlatParams({k: tensors[k] for k in self.ORDER if k in tensors}, device)
         self.p = self.params.p
         self.grads = FlatGrads.mirroring(self.params)
         M = self.params.shapes["shs"][1]

@@ -198,6 +198,30 @@ int gsr_surface_backward(const float* allmap, const float* raymat, float depth_r
                          const float* surf_depth, const float* g_surf_depth, const float* g_surf_normal, float* g_allmap,
                          void* stream);
 
+/* Densification bookkeeping.
+ * gsr_densification_stats: GaussianModel.add_densification_stats (scene/gaussian_model.py:578-584) fused with the
+ *   max_radii2D update of train.py:243.  grad_means2D float[P,3] (viewspace_points.grad), radii int32[P]
+ *   (update filter = radii > 0), gaussian_weights float[P]; the five float[P] statistics are updated in place.
+ * gsr_gather_rows: applies one row map to several row-major blocks of a flat buffer: for every group g and new row r,
+ *   dst[g.dst_offset + r*g.width + c] = row_map[r] >= 0 ? src[g.src_offset + row_map[r]*g.width + c] : 0.
+ *   This is _prune_optimizer / cat_tensors_to_optimizer (scene/gaussian_model.py:403-484) for parameters and both Adam
+ *   moments in ONE pass per buffer (new rows of the moments use map -1 = zeros, as torch.zeros_like there).
+ *   row_map int32[n_rows] (device); groups: host array, at most 16; offsets in floats.
+ * gsr_split_children: the new positions and scalings of densify_and_split (scene/gaussian_model.py:508-526):
+ *   child j of parent[j]: xyz = R(q) (exp(scaling) * noise_j, 0) + xyz, scaling = log(exp(scaling) / (0.8 N)); noise
+ *   float[n_children, scale_dims] standard normal supplied by the caller; scale_dims 2 (surfels) or 3. */
+typedef struct {
+	uint64_t src_offset, dst_offset;
+	uint32_t width;
+} gsr_gather_group;
+int gsr_densification_stats(int P, const float* grad_means2D, const int* radii, const float* gaussian_weights,
+                            float* xyz_gradient_accum, float* denom, float* accum_w, float* denom_w, float* max_radii2D,
+                            void* stream);
+int gsr_gather_rows(const float* src, float* dst, const int* row_map, uint64_t n_rows, const gsr_gather_group* groups,
+                    int num_groups, void* stream);
+int gsr_split_children(int n_children, int scale_dims, int N, const int* parent, const float* xyz, const float* scaling,
+                       const float* rotation, const float* noise, float* child_xyz, float* child_scaling, void* stream);
+
 /* gsr_adam_step: torch.optim.Adam(lr per group, betas, eps, amsgrad=False, weight_decay=0) as the reference sets it up
  * (scene/gaussian_model.py:196-209: eight groups, eps = 1e-15), fused over ONE flat buffer: param, grad, exp_avg and
  * exp_avg_sq are float[n], 16-byte aligned, laid out identically.  `segments` (host array, at most 16, tiling [0, n) in
