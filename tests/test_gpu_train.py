@@ -194,3 +194,73 @@ def test_train_state_step_end_to_end():
         # step 1: m/(1-b1) = g, sqrt(v/(1-b2)) = |g|  ->  update = -lr * sign(g) (eps = 1e-15 is negligible)
         if period == 0:
             assert torch.allclose(d[nz], -lr * torch.sign(g[nz]), rtol=1e-3, atol=lr * 1e-3 + ulp), k
+
+
+def test_training_loop_converges_and_survives_densification():
+    """The pieces together, as train.py:120-306 strings them: render() (rasterizer + fused surface pass + fused
+    reflection) -> photometric + normal-consistency loss -> backward into the flat buffer -> fused Adam, with the
+    densification statistics every step and one densify_and_prune in the middle.  Target: an image rendered from the
+    unperturbed scene; the perturbed model must get closer to it."""
+    import gsr_synth as S
+    from gaussian_renderer import render
+    from gsr_densify import DensifyStats, densify_and_prune
+    from gsr_train import GaussianTrainState
+    from utils.loss_utils import photometric_loss
+    P, W, H, L = 6000, 160, 120, 16
+    sc = S.make_scene(P, "S", seed=13, mu=-2.7)
+    tex, fail = S.make_cubemap(L, 3, 13)
+    cam = S.make_camera(W, H)
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+
+    class View:
+        FoVx, FoVy = 2 * np.arctan(cam["tanfovx"]), 2 * np.arctan(cam["tanfovy"])
+        image_width, image_height = W, H
+        world_view_transform, full_proj_transform, camera_center = ct["viewmatrix"], ct["projmatrix"], ct["campos"]
+        HWK, R, T = (H, W, cam["K"]), ct["R"], ct["T"]
+        znear, zfar = 0.01, 100.0
+
+    class Pipe:
+        depth_ratio, compute_cov3D_python, fused_reflection, fused_surface = 0.0, False, True, True
+
+    def model_of(st):
+        class Env:
+            params = {"Cubemap_texture": st.p["cubemap"], "Cubemap_failv": st.p["fail"]}
+
+        class PC:
+            get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_refl = (st.p["means3D"], st.p["opacities"], st.p["scales"],
+                                                                                       st.p["rotations"], st.p["shs"], st.p["refl_strengths"])
+            active_sh_degree, get_envmap = 3, Env
+        return PC
+
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
+    truth = {k: torch.from_numpy(sc[k]) for k in names}
+    truth["cubemap"], truth["fail"] = torch.from_numpy(tex), torch.from_numpy(fail)
+    bg = torch.zeros(3, device="cuda")
+    with torch.no_grad():
+        gt = render(View, model_of(GaussianTrainState(truth, "cuda")), Pipe, bg)["render"].detach().clone()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    start = {k: v.clone() for k, v in truth.items()}
+    start["shs"] = start["shs"] + 0.3 * torch.randn(start["shs"].shape, generator=g)
+    start["opacities"] = start["opacities"] * 0.7
+    st = GaussianTrainState(start, "cuda", spatial_lr_scale=1.0)
+    stats = DensifyStats(P, "cuda")
+    losses = []
+    for it in range(1, 41):
+        st.update_learning_rate(it)
+        st.grads.zero_()
+        pkg = render(View, model_of(st), Pipe, bg)
+        loss = photometric_loss(pkg["render"], gt, 0.2)
+        normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]      # train.py:182-189
+        loss = loss + 0.05 * normal_error.mean()
+        loss.backward()
+        losses.append(float(photometric_loss(pkg["render"].detach(), gt, 0.2)))
+        stats.update(pkg["viewspace_points"].grad, pkg["radii"], pkg["gaussian_weights"])
+        st.optimizer.step()
+        if it == 20:
+            st, stats, info = densify_and_prune(st, stats, 0.0002, 0.05, torch.zeros(3), 5.0, None)
+            assert info["after"] == st.p["means3D"].shape[0] and info["after"] > 0
+    assert np.isfinite(losses).all()
+    # before the densification step the fit improves steadily; pruning by blend weight (accum_w < 0.01, as the reference
+    # does) removes many of the synthetic scene's half-hidden surfels at once, after which the fit improves again
+    assert np.mean(losses[16:20]) < 0.8 * np.mean(losses[:3]), (losses[:3], losses[16:20])
+    assert np.mean(losses[-3:]) < np.mean(losses[20:23]), (losses[20:23], losses[-3:])
