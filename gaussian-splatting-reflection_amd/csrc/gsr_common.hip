@@ -9,6 +9,8 @@
 #include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace gsr {
 
@@ -72,14 +74,28 @@ uint32_t higher_msb(uint32_t n) {
 	return msb;
 }
 
+// rocPRIM switches radix_sort_pairs to a merge sort below 1 Mi items (~22 small launches, 165 us for 1e6 pairs on MI355X);
+// Onesweep (histogram + one launch per 8 key bits) is ~3x faster there, so the switch point is lowered to 64 Ki items.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
+// tiles_touched read through the depth order: element i of the sequence the second scan runs over
+struct TouchedInOrder {
+	const uint32_t* tiles_touched;
+	__host__ __device__ uint32_t operator()(uint32_t idx) const { return tiles_touched[idx]; }
+};
+// bytes of the P-sized temp region: the larger of (scan, scan through the order, depth pre-sort)
 size_t scan_temp_bytes(size_t P) {
-	size_t bytes = 0;
-	(void)rocprim::inclusive_scan(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
-	return bytes;
+	size_t a = 0, b = 0, c = 0;
+	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
+	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
+	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
+	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+	                                (uint32_t*)nullptr, P, 0, 31, 0, false);
+	return std::max(a, std::max(b, c));
 }
 size_t sort_temp_bytes(size_t R, int end_bit) {
 	size_t bytes = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
+	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
 	                                end_bit, 0, false);
 	return bytes;
 }
@@ -98,6 +114,9 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.aux = c.take<float>(P * aux_floats);
 	g.acc = c.take<float>(P * acc_floats);
 	g.flags = c.take<int>(4);
+	g.depth_sorted = c.take<uint32_t>(P);
+	g.order = c.take<uint32_t>(P);
+	g.offsets_sorted = c.take<uint32_t>(P);
 	g.scan_temp = c.take<char>(scan_bytes);
 	g.scan_temp_bytes = scan_bytes;
 	if (total) *total = c.size();
@@ -115,51 +134,65 @@ ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int pla
 BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total) {
 	Carver c(buf);
 	BinningState b;
-	b.keys_unsorted = c.take<uint64_t>(R);
-	b.keys = c.take<uint64_t>(R);
-	b.vals_unsorted = c.take<uint32_t>(R);
 	b.point_list = c.take<uint32_t>(R);
+	b.tile_keys = c.take<uint32_t>(R);
+	b.tile_keys_unsorted = c.take<uint32_t>(R);
+	b.vals_unsorted = c.take<uint32_t>(R);
 	b.sort_temp = c.take<char>(sort_bytes);
 	b.sort_temp_bytes = sort_bytes;
 	if (total) *total = c.size();
 	return b;
 }
 
-// duplicateWithKeys (DSR/DGR rasterizer_impl.cu:70-111).  The tile rect was computed once in preprocess
-// and is read back packed, so this kernel is pure integer work: key = tile<<32 | depth bits, value = idx,
-// emission order y outer / x inner.
-__global__ void __launch_bounds__(256) emit_keys_kernel(int P, const uint32_t* __restrict__ rect, const float* __restrict__ depths,
-                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t tiles_x) {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= P) return;
+// duplicateWithKeys + SortPairs (DSR/DGR rasterizer_impl.cu:70-111, 308-313), restructured as a TWO-LEVEL sort.
+// The reference sorts R (tile << 32 | depth bits) 64-bit keys: 6 radix passes over R pairs (152 B per instance).  The
+// same order — tile, then depth bits, then Gaussian index (stable) — is obtained by
+//   1. a stable sort of the P Gaussians by depth bits (4 passes over P pairs, P << R),
+//   2. emitting the (tile, index) instances in THAT order, and
+//   3. a stable sort of the R instances by tile id alone (2 passes for <= 16 tile bits),
+// since a stable sort by tile keeps instances of one tile in emission (= depth, index) order.  point_list is bit-identical
+// to the reference's; the 64-bit keys exist only as a debug reconstruction (gsr_debug_fetch "keys").
+// Emission order inside a Gaussian: y outer / x inner, as the reference.
+__global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
+                                                         const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
+                                                         uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	const uint32_t idx = order[i];
 	if (tiles_touched[idx] == 0) return;
-	uint32_t off = (idx == 0) ? 0u : offsets[idx - 1];
+	uint32_t off = (i == 0) ? 0u : offsets_sorted[i - 1];
 	const uint32_t r0 = rect[2 * idx], r1 = rect[2 * idx + 1];
 	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
-	const uint64_t dbits = (uint64_t)__float_as_uint(depths[idx]);
 	for (uint32_t y = y0; y < y1; y++)
 		for (uint32_t x = x0; x < x1; x++) {
-			keys[off] = ((uint64_t)(y * tiles_x + x) << 32) | dbits;
-			vals[off] = (uint32_t)idx;
+			tile_keys[off] = y * tiles_x + x;
+			vals[off] = idx;
 			off++;
 		}
 }
 
 // identifyTileRanges (DSR/DGR rasterizer_impl.cu:116-138)
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= L) return;
-	const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+	const uint32_t currtile = tile_keys[idx];
 	if (idx == 0) ranges[currtile].x = 0;
 	else {
-		const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+		const uint32_t prevtile = tile_keys[idx - 1];
 		if (currtile != prevtile) {
 			ranges[prevtile].y = idx;
 			ranges[currtile].x = idx;
 		}
 	}
 	if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// debug only: the reference's sorted 64-bit keys, rebuilt from the sorted tile ids and the depth of each instance
+__global__ void __launch_bounds__(256) rebuild_keys_kernel(int L, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
+                                                           const float* __restrict__ depths, uint64_t* __restrict__ keys) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= L) return;
+	keys[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
 }
 
 // One pinned host word per host thread for the num_rendered readback (the reference does a blocking
@@ -185,14 +218,31 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
 		GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));
 	}
-	GSR_HIP_CHECK(hipStreamSynchronize(stream));
+	// the host waits on THIS point only, not on the level-1 work enqueued behind it
+	static thread_local hipEvent_t readback_done = nullptr;
+	if (!readback_done) GSR_HIP_CHECK(hipEventCreateWithFlags(&readback_done, hipEventDisableTiming));
+	GSR_HIP_CHECK(hipEventRecord(readback_done, stream));
+	{
+		// level 1 (independent of num_rendered, so it runs while the host waits for the read-back): depth order of the
+		// Gaussians (31 key bits: depths are positive floats, their bit patterns order like the values) and the scan of
+		// tiles_touched taken in that order
+		StageTimer st_(GSR_STAGE_SORT, stream);
+		size_t tmp = geom.scan_temp_bytes;
+		GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+		                                        rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
+		tmp = geom.scan_temp_bytes;
+		auto touched = rocprim::make_transform_iterator((const uint32_t*)geom.order, TouchedInOrder{geom.tiles_touched});
+		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, touched, geom.offsets_sorted, (size_t)P, rocprim::plus<uint32_t>(), stream,
+		                                      false));
+	}
+	GSR_HIP_CHECK(hipEventSynchronize(readback_done));
 	const int R = host[0];
 	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
 	if (R < 0) { set_error("num_rendered overflowed int32"); return GSR_E_INVALID; }
 
 	const uint32_t tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
 	const int bit = (int)higher_msb(tiles);
-	const size_t sort_bytes = R > 0 ? sort_temp_bytes((size_t)R, 32 + bit) : 0;
+	const size_t sort_bytes = R > 0 ? sort_temp_bytes((size_t)R, bit) : 0;
 	size_t total = 0;
 	carve_binning(nullptr, (size_t)R, sort_bytes, &total);
 	void* buf = alloc(alloc_user, GSR_BUF_BINNING, total);
@@ -203,16 +253,16 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
-		emit_keys_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.rect, geom.depths, geom.point_offsets, geom.tiles_touched, b.keys_unsorted,
-		                                                      b.vals_unsorted, (uint32_t)tiles_x); }
+		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
+		                                                       b.vals_unsorted, (uint32_t)tiles_x); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
-		{ StageTimer st_(GSR_STAGE_SORT, stream);
-		GSR_HIP_CHECK(rocprim::radix_sort_pairs(b.sort_temp, sb, b.keys_unsorted, b.keys, b.vals_unsorted, b.point_list, (size_t)R, 0u,
-		                                        (unsigned)(32 + bit), stream, false)); }
+		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
+		GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, sb, b.tile_keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0u,
+		                                        (unsigned)bit, stream, false)); }
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
 		{ StageTimer st_(GSR_STAGE_RANGES, stream);
-		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.keys, img.ranges); }
+		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.tile_keys, img.ranges); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	return R;
@@ -334,7 +384,12 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	if (n == "transMat" && variant == 0) return gather(2, 9);
 	if (n == "cov3D" && variant == 1) return d2d(g.aux, (size_t)P * 6 * 4);
 	if (n == "point_list") return d2d(b.point_list, (size_t)R * 4);
-	if (n == "keys") return d2d(b.keys, (size_t)R * 8);
+	if (n == "keys") {   // reference-format sorted keys, rebuilt (the product path sorts tile ids only)
+		if (R == 0) return 0;
+		rebuild_keys_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.tile_keys, b.point_list, g.depths, (uint64_t*)dst);
+		GSR_LAUNCH_CHECK(0, stream);
+		return 0;
+	}
 	if (n == "ranges") return d2d(im.ranges, tiles * 8);
 	if (n == "final_T") return d2d(im.final_T, HW * 4 * (variant == 0 ? 3 : 1));
 	if (n == "n_contrib") return d2d(im.n_contrib, HW * 4 * (variant == 0 ? 2 : 1));

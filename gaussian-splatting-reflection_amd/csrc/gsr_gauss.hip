@@ -88,6 +88,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
+	g.depths[idx] = __int_as_float(0x7f7fffff);   // culled: sorts behind every visible Gaussian in the depth pre-sort
 	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
 	const float* vm = cam.view;
 	const float* pm = cam.proj;

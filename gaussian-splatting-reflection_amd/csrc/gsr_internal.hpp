@@ -73,7 +73,10 @@ struct GeomState {
 	float* aux;              // G: cov3D P*6.  S: unused
 	float* acc;              // backward accumulator P*ACC_F (zeroed by backward)
 	int* flags;              // 4 ints: [0] prefiltered-trap flag
-	void* scan_temp;
+	uint32_t* depth_sorted;  // P        depth bits in ascending order (output of the depth pre-sort; keys only)
+	uint32_t* order;         // P        Gaussian index at each position of the depth order (stable: ties by index)
+	uint32_t* offsets_sorted;// P        inclusive scan of tiles_touched taken in depth order
+	void* scan_temp;         // shared by the two scans and the P-sized sort
 	size_t scan_temp_bytes;
 };
 struct ImageState {
@@ -82,10 +85,10 @@ struct ImageState {
 	uint32_t* n_contrib; // planes_n * H*W
 };
 struct BinningState {
-	uint64_t* keys_unsorted;
-	uint64_t* keys;
+	uint32_t* point_list;        // R  Gaussian index of each instance, ordered by (tile, depth, index)   [first: the backward finds it without sizes]
+	uint32_t* tile_keys;         // R  tile id of each instance, sorted
+	uint32_t* tile_keys_unsorted;
 	uint32_t* vals_unsorted;
-	uint32_t* point_list;
 	void* sort_temp;
 	size_t sort_temp_bytes;
 };

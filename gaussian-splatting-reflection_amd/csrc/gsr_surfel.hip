@@ -151,6 +151,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
+	g.depths[idx] = __int_as_float(0x7f7fffff);   // culled: sorts behind every visible Gaussian in the depth pre-sort
 	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
 	const float* vm = cam.view;
 	const float pvx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
