@@ -25,6 +25,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-corr
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
+# Per-file flags.  The tile kernels keep their per-Gaussian record in SGPRs; clang's SLP vectoriser turns pairs of
+# scalar FMAs into v_pk_* instructions whose SGPR operands must be even-aligned pairs, so it re-packs the freshly loaded
+# record with ~25 s_mov per (wave, Gaussian) pair and waits for the scalar load immediately instead of one pair later.
+# Scalar issue slots are as scarce as vector ones here (measured: tests/ablate notes in DESIGN.md), so SLP is off for them.
+EXTRA_FLAGS = {"gsr_surfel.hip": ["-fno-slp-vectorize"], "gsr_gauss.hip": ["-fno-slp-vectorize"]}
+if os.environ.get("GSR_SLP") == "1":      # development switch for A/B measurements
+    EXTRA_FLAGS = {}
+
+
 def _digest():
     h = hashlib.sha256()
     for f in SOURCES + HEADERS + ["build.py"]:
@@ -33,12 +42,13 @@ def _digest():
             with open(p, "rb") as fh:
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

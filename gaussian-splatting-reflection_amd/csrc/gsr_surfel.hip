@@ -326,21 +326,25 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
-		// ---- 2. blend
+		// ---- 2. blend.  Two SGPR record buffers ping-pong (as in the backward): the s_load of the next record is issued
+		// right after the ray-splat evaluation of the current one; with a single rotating buffer the compiler copies the 20
+		// SGPRs twice per pair (~25 of the ~60 scalar instructions per pair, and SALU issue is as scarce as VALU issue).
 		unsigned long long touched = 0ull;
-		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * S_REC_F4;
-		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3], n4 = rp[4];
-		for (int k = 0; k < nh; k++) {
-			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3, r4 = n4;
+		struct Rec { float4 r0, r1, r2, r3, r4; };
+		auto fetch = [&](int k) -> Rec {
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
+			return Rec{q[0], q[1], q[2], q[3], q[4]};
+		};
+		// returns true when every pixel of the block has retired
+		auto blend = [&](int k, const Rec& R, auto&& prefetch_next) -> bool {
 			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
 			// straight-line for all 64 lanes: a lane whose pair does not contribute blends with weight 0 (the identity of
 			// every accumulator) instead of sitting out in an exec-mask region
 			SurfelPair o;
-			const bool pair_ok = surfel_pair<true>(r0, r1, r2, r3.z, pixx, pixy, o);
-			if (k + 1 < nh) {
-				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * S_REC_F4;
-				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-			}
+			const bool pair_ok = surfel_pair<true>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			__builtin_amdgcn_sched_barrier(0);
+			prefetch_next();
+			__builtin_amdgcn_sched_barrier(0);
 			const float test_T = T * (1 - o.alpha);
 			const bool live = !done && pair_ok;
 			const bool sat = live && test_T < 0.0001f;   // this pixel is saturated: the pair is dropped and the pixel retires
@@ -359,10 +363,10 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 				const bool med = ok && T > 0.5f;
 				median_depth = med ? depth : median_depth;
 				median_contributor = med ? (float)contributor : median_contributor;
-				N0 = fmaf(r2.w, w, N0); N1 = fmaf(r3.x, w, N1); N2 = fmaf(r3.y, w, N2);
-				C0 = fmaf(r3.w, w, C0); C1 = fmaf(r4.x, w, C1); C2 = fmaf(r4.y, w, C2);
-				RS = fmaf(r4.z, w, RS);
-				mask = (ok && r4.w != 0.f) ? 1.0f : mask;
+				N0 = fmaf(R.r2.w, w, N0); N1 = fmaf(R.r3.x, w, N1); N2 = fmaf(R.r3.y, w, N2);
+				C0 = fmaf(R.r3.w, w, C0); C1 = fmaf(R.r4.x, w, C1); C2 = fmaf(R.r4.y, w, C2);
+				RS = fmaf(R.r4.z, w, RS);
+				mask = (ok && R.r4.w != 0.f) ? 1.0f : mask;
 				T = ok ? test_T : T;
 				last_contributor = ok ? contributor : last_contributor;
 				// gaussian_weights (forward.cu:458-459): max over the wave's pixels; merged across waves by atomicMax
@@ -370,7 +374,13 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 				if (lane == 63) s_wmax[k] = wm;
 				touched |= 1ull << k;
 			}
-			if (__ballot(sat) != 0ull && __ballot(!done) == 0ull) break;
+			return __ballot(sat) != 0ull && __ballot(!done) == 0ull;
+		};
+		Rec A = fetch(0), B = A;
+		for (int k = 0; k < nh; k += 2) {
+			if (blend(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); })) break;
+			if (k + 1 >= nh) break;
+			if (blend(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); })) break;
 		}
 		__syncthreads();
 		// ---- 3. w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
