@@ -29,7 +29,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-corr
 # scalar FMAs into v_pk_* instructions whose SGPR operands must be even-aligned pairs, so it re-packs the freshly loaded
 # record with ~25 s_mov per (wave, Gaussian) pair and waits for the scalar load immediately instead of one pair later.
 # Scalar issue slots are as scarce as vector ones here (measured: tests/ablate notes in DESIGN.md), so SLP is off for them.
-EXTRA_FLAGS = {"gsr_surfel.hip": ["-fno-slp-vectorize"], "gsr_gauss.hip": ["-fno-slp-vectorize"]}
+# Variant G's record is 16 dwords and its conic math packs without re-shuffling: there SLP helps (fwd 0.44 vs 0.56 ms at
+# 1 M Gaussians), so only the surfel kernels opt out (fwd 1.24 -> 1.15 ms, bwd 2.43 -> 2.10 ms at C3).
+EXTRA_FLAGS = {"gsr_surfel.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("GSR_SLP") == "1":      # development switch for A/B measurements
     EXTRA_FLAGS = {}
 
