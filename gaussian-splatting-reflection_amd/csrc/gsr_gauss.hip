@@ -245,18 +245,20 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
 		__syncthreads();
-		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * G_REC_F4;
-		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3];
-		for (int k = 0; k < nh; k++) {
-			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+		// two SGPR record buffers ping-pong so that the next record's s_load stays in flight for a whole pair
+		struct Rec { float4 r0, r1, r2, r3; };
+		auto fetch = [&](int k) -> Rec {
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * G_REC_F4;
+			return Rec{q[0], q[1], q[2], q[3]};
+		};
+		auto blend = [&](int k, const Rec& R, auto&& prefetch_next) -> bool {   // true: every pixel of the block has retired
 			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
 			// straight-line for all 64 lanes: a rejected pair blends with weight 0 (see surfel_render_fwd_wave_kernel)
 			float dx, dy, G, alpha;
-			const bool pair_ok = gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, G, alpha);
-			if (k + 1 < nh) {
-				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
-				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
-			}
+			const bool pair_ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, G, alpha);
+			__builtin_amdgcn_sched_barrier(0);
+			prefetch_next();
+			__builtin_amdgcn_sched_barrier(0);
 			const float test_T = T * (1 - alpha);
 			const bool live = !done && pair_ok;
 			const bool sat = live && test_T < 0.0001f;
@@ -264,14 +266,20 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			done = done || sat;
 			if (__ballot(ok) != 0ull) {
 				const float w = ok ? alpha * T : 0.f;
-				C0 = fmaf(r1.z, w, C0); C1 = fmaf(r1.w, w, C1); C2 = fmaf(r2.x, w, C2);
-				N0 = fmaf(r2.y, w, N0); N1 = fmaf(r2.z, w, N1); N2 = fmaf(r2.w, w, N2);
-				RS = fmaf(r3.x, w, RS);
-				if (INVDEPTH) ID = fmaf(r3.y, w, ID);
+				C0 = fmaf(R.r1.z, w, C0); C1 = fmaf(R.r1.w, w, C1); C2 = fmaf(R.r2.x, w, C2);
+				N0 = fmaf(R.r2.y, w, N0); N1 = fmaf(R.r2.z, w, N1); N2 = fmaf(R.r2.w, w, N2);
+				RS = fmaf(R.r3.x, w, RS);
+				if (INVDEPTH) ID = fmaf(R.r3.y, w, ID);
 				T = ok ? test_T : T;
 				last_contributor = ok ? contributor : last_contributor;
 			}
-			if (__ballot(sat) != 0ull && __ballot(!done) == 0ull) break;
+			return __ballot(sat) != 0ull && __ballot(!done) == 0ull;
+		};
+		Rec A = fetch(0), B = A;
+		for (int k = 0; k < nh; k += 2) {
+			if (blend(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); })) break;
+			if (k + 1 >= nh) break;
+			if (blend(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); })) break;
 		}
 	}
 	if (inside) {
@@ -368,19 +376,20 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
 		unsigned long long touched = 0ull;
-		const float4* rp = rec + (size_t)__builtin_amdgcn_readlane(hid, 0) * G_REC_F4;
-		float4 n0 = rp[0], n1 = rp[1], n2 = rp[2], n3 = rp[3];
-		for (int k = 0; k < nh; k++) {
-			const float4 r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+		struct Rec { float4 r0, r1, r2, r3; };
+		auto fetch = [&](int k) -> Rec {
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * G_REC_F4;
+			return Rec{q[0], q[1], q[2], q[3]};
+		};
+		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
 			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			float dx, dy, Gp, alpha_p;
-			const bool pair_ok = gauss_pair(r0, r1.x, r1.y, pixx, pixy, dx, dy, Gp, alpha_p);   // all lanes: fields must be defined
+			const bool pair_ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, Gp, alpha_p);   // all lanes: fields must be defined
 			const bool ok = inside && contributor < last_contributor && pair_ok;
-			if (k + 1 < nh) {
-				const float4* np = rec + (size_t)__builtin_amdgcn_readlane(hid, k + 1) * G_REC_F4;
-				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
-			}
-			if (__ballot(ok) == 0ull) continue;
+			__builtin_amdgcn_sched_barrier(0);
+			prefetch_next();
+			__builtin_amdgcn_sched_barrier(0);
+			if (__ballot(ok) == 0ull) return;
 			// Straight-line for all 64 lanes: a rejected pair runs with alpha = 0 (the identity of the recurrences) and
 			// G = 0, and has its root gradients zeroed, so every v[] comes out 0 without exec-mask regions.
 			float v[G_ACC_F];
@@ -388,9 +397,9 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			const float inv_1ma = div_nr(1.0f, 1.f - alpha);
 			T *= inv_1ma;
 			const float w = alpha * T;
-			float D1 = r1.z * dp0 + r1.w * dp1 + r2.x * dp2 + r2.y * dn0 + r2.z * dn1 + r2.w * dn2 + r3.x * dr;
-			if (INVDEPTH) D1 += r3.y * di;
-			const float D2 = r1.z * dp0x3 + r1.w * dp1x2 + r2.x * dp2;
+			float D1 = R.r1.z * dp0 + R.r1.w * dp1 + R.r2.x * dp2 + R.r2.y * dn0 + R.r2.z * dn1 + R.r2.w * dn2 + R.r3.x * dr;
+			if (INVDEPTH) D1 += R.r3.y * di;
+			const float D2 = R.r1.z * dp0x3 + R.r1.w * dp1x2 + R.r2.x * dp2;
 			A1 = last_alpha * D1p + (1.f - last_alpha) * A1;
 			A2 = last_alpha * D2p + (1.f - last_alpha) * A2;
 			D1p = D1; D2p = D2; last_alpha = alpha;
@@ -405,11 +414,11 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			v[GA_NORMAL + 2] = w * dn2;
 			v[GA_REFL] = w * dr;
 			v[GA_INVD] = INVDEPTH ? w * di : 0.f;
-			const float dL_dG = r1.y * dL_dalpha;
-			const float dL_dG_means2d = r1.y * dL_dalpha_means2d;
+			const float dL_dG = R.r1.y * dL_dalpha;
+			const float dL_dG_means2d = R.r1.y * dL_dalpha_means2d;
 			const float gdx = G * dx, gdy = G * dy;
-			const float dG_ddelx = (-gdx * r0.z - gdy * r0.w) * ddelx_dx;
-			const float dG_ddely = (-gdy * r1.x - gdx * r0.w) * ddely_dy;
+			const float dG_ddelx = (-gdx * R.r0.z - gdy * R.r0.w) * ddelx_dx;
+			const float dG_ddely = (-gdy * R.r1.x - gdx * R.r0.w) * ddely_dy;
 			v[GA_MEAN2D + 0] = dL_dG * dG_ddelx;
 			v[GA_MEAN2D + 1] = dL_dG * dG_ddely;
 			v[GA_MEAN2DP + 0] = dL_dG_means2d * dG_ddelx;
@@ -429,6 +438,12 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 				for (int g = 0; g < 4; g++) slab[4 * g] = z[g];
 			}
 			touched |= 1ull << k;
+		};
+		Rec A = fetch(0), B = A;
+		for (int k = 0; k < nh; k += 2) {
+			differentiate(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); });
+			if (k + 1 >= nh) break;
+			differentiate(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); });
 		}
 		__syncthreads();
 		if (touched != 0ull) {
