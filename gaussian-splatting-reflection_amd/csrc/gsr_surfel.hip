@@ -646,19 +646,15 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	}
 }
 
-#define GSR_DEF_SURFEL_BWD_WAVE(NAME, WPE)                                                                                                  \
-	__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                                                     \
-	NAME(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,                   \
-	     const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,             \
-	     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,                   \
-	     const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {                             \
-		surfel_render_bwd_wave_body(ranges, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib,          \
-		                            dL_dpixels, dL_depths, dL_drefl_map, acc);                                                               \
-	}
-GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w3, 3)
-GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w4, 4)
-GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w5, 5)
-GSR_DEF_SURFEL_BWD_WAVE(surfel_render_bwd_wave_kernel_w6, 6)
+// 71 VGPRs.  Measured at C3 with amdgpu_waves_per_eu = 4 / 5 / 6 / unconstrained (7): 2.11 / 2.07 / 2.04 / 2.13 ms.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
+surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
+                              const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                              const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
+	surfel_render_bwd_wave_body(ranges, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
+	                            dL_depths, dL_drefl_map, acc);
+}
 
 // quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
 __device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, const M3& v_R, float* v_quat) {
@@ -910,9 +906,7 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 		const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
-		const int wpe = (option_dev() >> 4) & 15;
-		auto kern = wpe == 3 ? surfel_render_bwd_wave_kernel_w3 : wpe == 5 ? surfel_render_bwd_wave_kernel_w5
-		          : wpe == 6 ? surfel_render_bwd_wave_kernel_w6 : surfel_render_bwd_wave_kernel_w4;
+		auto kern = surfel_render_bwd_wave_kernel;
 		kern<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
 		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
