@@ -1,0 +1,160 @@
+"""Shared host side of the two rasterizer packages.
+
+`diff_surfel_rasterization` (variant S) and `diff_gaussian_rasterization` (variant G) expose the same three public
+objects as the reference's packages of those names — `GaussianRasterizationSettings`, `GaussianRasterizer`,
+`rasterize_gaussians` (+ the autograd Function `_RasterizeGaussians`) — and differ only in which per-Gaussian tensors
+they take and which maps they return.  Instead of two hand-written copies, both are produced here from a small
+description of the variant (`Variant`): the order of the positional tensors, which of them may be omitted, how the
+arguments of the `_C` entry points are laid out, and which outputs are differentiable.
+
+Reference surfaces reproduced (argument names, order, defaults, return tuples, exception texts):
+  S: submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py:21-240
+  G: submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py:20-225
+"""
+import inspect
+from collections import namedtuple
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+SETTINGS_COMMON = ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree",
+                   "campos", "prefiltered", "debug")
+MSG_COLOR = 'Please provide excatly one of either SHs or precomputed colors!'        # (sic) the reference's wording
+MSG_COV = 'Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!'
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    """Host copies of every tensor of an argument tuple (used by the debug snapshot path)."""
+    return tuple(x.cpu().clone() if isinstance(x, torch.Tensor) else x for x in input_tuple)
+
+
+@dataclass
+class Variant:
+    c_module: object                                   # the package's _C module (ctypes-backed)
+    extra_settings: Tuple[str, ...]                    # settings fields after the common twelve
+    tensors: Tuple[str, ...]                           # positional tensors of Function.apply, in order (settings excluded)
+    settings_pos: int                                  # where raster_settings sits among apply()'s arguments
+    forward_kwargs: Tuple[Tuple[str, object], ...]     # GaussianRasterizer.forward signature after (means3D, means2D, opacities)
+    module_to_apply: Dict[str, str]                    # forward() keyword -> apply() tensor name where they differ
+    placeholder: Callable                              # (name, device) -> tensor standing in for an omitted optional input
+    pack_forward: Callable                             # (tensors dict, settings) -> args of _C.rasterize_gaussians
+    split_forward: Callable                            # _C return tuple -> (num_rendered, outputs, buffers, radii)
+    nondiff_outputs: Tuple[int, ...]                   # indices of `outputs` marked non-differentiable
+    saved: Tuple[str, ...]                             # tensors kept for the backward
+    pack_backward: Callable                            # (saved dict, settings, grad_outputs, num_rendered, buffers, radii) -> _C args
+    grads_of: Callable                                 # _C backward return tuple -> dict tensor name -> gradient
+    optional_grads: Tuple[str, ...]                    # inputs whose gradient is None when they were passed as placeholders
+    sinkable: Dict[str, str] = field(default_factory=dict)   # apply() tensor name -> gradient-sink key (S only)
+    snapshot_on_debug: bool = False
+
+
+def build_api(v: Variant):
+    Settings = namedtuple("GaussianRasterizationSettings", SETTINGS_COMMON + v.extra_settings)
+    n_args = len(v.tensors) + 1
+
+    def split_args(args):
+        args = list(args)
+        settings = args.pop(v.settings_pos)
+        return dict(zip(v.tensors, args)), settings
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *args):
+            t, settings = split_args(args)
+            c_args = v.pack_forward(t, settings)
+            if v.snapshot_on_debug and settings.debug:
+                host_copy = cpu_deep_copy_tuple(c_args)          # taken before anything can corrupt the inputs
+                try:
+                    ret = v.c_module.rasterize_gaussians(*c_args)
+                except Exception as ex:
+                    torch.save(host_copy, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                ret = v.c_module.rasterize_gaussians(*c_args)
+            num_rendered, outputs, buffers, radii = v.split_forward(ret)
+            ctx.raster_settings, ctx.num_rendered = settings, num_rendered
+            ctx.save_for_backward(*[t[k] for k in v.saved], radii, *buffers)
+            ctx.mark_non_differentiable(*[outputs[i] for i in v.nondiff_outputs])
+            return outputs
+
+        @staticmethod
+        def backward(ctx, *grad_outputs):
+            settings = ctx.raster_settings
+            kept = ctx.saved_tensors
+            saved = dict(zip(v.saved, kept[:len(v.saved)]))
+            radii, buffers = kept[len(v.saved)], kept[len(v.saved) + 1:]
+            c_args = v.pack_backward(saved, settings, grad_outputs, ctx.num_rendered, buffers, radii)
+            if v.snapshot_on_debug and settings.debug:
+                host_copy = cpu_deep_copy_tuple(c_args)
+                try:
+                    ret = v.c_module.rasterize_gaussians_backward(*c_args)
+                except Exception as ex:
+                    torch.save(host_copy, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                ret = v.c_module.rasterize_gaussians_backward(*c_args)
+            g = v.grads_of(ret)
+            sink = getattr(v.c_module, "grad_sink", None) or {}
+            out = []
+            for name in v.tensors:
+                grad = g.get(name)
+                if name in v.sinkable and v.sinkable[name] in sink:
+                    grad = None            # already written into the caller's sink tensor (see _C.set_grad_sink)
+                elif name in v.optional_grads and (saved.get(name) is None or saved[name].numel() == 0):
+                    grad = None            # autograd wants None for inputs that were passed as empty placeholders
+                out.append(grad)
+            out.insert(v.settings_pos, None)
+            return tuple(out)
+
+    def rasterize_gaussians(*args):
+        if len(args) != n_args:
+            raise TypeError(f"rasterize_gaussians() takes {n_args} positional arguments but {len(args)} were given")
+        return _RasterizeGaussians.apply(*args)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            """Boolean mask of the points in front of the camera's near plane (frustum test of the rasterizer)."""
+            s = self.raster_settings
+            with torch.no_grad():
+                return v.c_module.mark_visible(positions, s.viewmatrix, s.projmatrix)
+
+        def _forward(self, means3D, means2D, opacities, **kw):
+            if (kw["shs"] is None) == (kw["colors_precomp"] is None):
+                raise Exception(MSG_COLOR)
+            have_sr = kw["scales"] is not None and kw["rotations"] is not None
+            have_any_sr = kw["scales"] is not None or kw["rotations"] is not None
+            if (not have_sr and kw["cov3D_precomp"] is None) or (have_any_sr and kw["cov3D_precomp"] is not None):
+                raise Exception(MSG_COV)
+            t = {"means3D": means3D, "means2D": means2D, "opacities": opacities}
+            for key, value in kw.items():
+                name = v.module_to_apply.get(key, key)
+                t[name] = v.placeholder(name, means3D.device) if value is None and name in PLACEHOLDERS else value
+            args = [t[name] for name in v.tensors]
+            args.insert(v.settings_pos, self.raster_settings)
+            return rasterize_gaussians(*args)
+
+    PLACEHOLDERS = {"sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp", "env_scope_mask"}
+    # give forward() the reference's explicit signature (keyword names and defaults are part of the API)
+    params = [inspect.Parameter("self", inspect.Parameter.POSITIONAL_OR_KEYWORD)]
+    params += [inspect.Parameter(n, inspect.Parameter.POSITIONAL_OR_KEYWORD) for n in ("means3D", "means2D", "opacities")]
+    params += [inspect.Parameter(n, inspect.Parameter.POSITIONAL_OR_KEYWORD, default=d) for n, d in v.forward_kwargs]
+    sig = inspect.Signature(params)
+
+    def forward(*args, **kwargs):
+        b = sig.bind(*args, **kwargs)
+        b.apply_defaults()
+        a = dict(b.arguments)
+        self = a.pop("self")
+        return self._forward(a.pop("means3D"), a.pop("means2D"), a.pop("opacities"), **a)
+    forward.__signature__ = sig
+    forward.__doc__ = "Same arguments and return tuple as the reference's GaussianRasterizer.forward."
+    GaussianRasterizer.forward = forward
+    return Settings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

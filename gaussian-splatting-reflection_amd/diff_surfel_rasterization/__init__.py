@@ -1,147 +1,72 @@
-"""MI355X drop-in for the reference's `diff_surfel_rasterization` package
-(submodules/diff-surfel-rasterization/diff_surfel_rasterization/__init__.py): same
-`GaussianRasterizationSettings` / `GaussianRasterizer` / `rasterize_gaussians` surface, same
-argument meaning and error behaviour, backed by hand-written HIP kernels (libgsr_hip.so).
+"""MI355X drop-in for the reference's `diff_surfel_rasterization` package (variant S, the 2D-surfel rasterizer the
+reference's `gaussian_renderer` calls): same `GaussianRasterizationSettings` / `GaussianRasterizer` /
+`rasterize_gaussians` surface, argument meaning and error behaviour, backed by hand-written HIP kernels (libgsr_hip.so).
 
-Returns of GaussianRasterizer.forward (reference __init__.py:106):
+GaussianRasterizer.forward(means3D, means2D, opacities, shs=None, colors_precomp=None, refl_strengths=None, scales=None,
+rotations=None, cov3D_precomp=None, env_scope_mask=None) returns
     (color[3,H,W], radii[P] int32, allmap[8,H,W], refl_strength_map[1,H,W], gaussian_weights[P])
 allmap planes: 0 depth, 1 alpha, 2-4 view-space normal, 5 median depth, 6 distortion, 7 env-scope mask.
+Everything variant-independent lives in `_raster_api.py`; this file only describes variant S.
 """
-from typing import NamedTuple
-
 import torch
-import torch.nn as nn
 
+from _raster_api import Variant, build_api, cpu_deep_copy_tuple  # noqa: F401
 from . import _C
 
 
-def cpu_deep_copy_tuple(input_tuple):
-    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
-    return tuple(copied_tensors)
+def _pack_forward(t, s):
+    return (s.bg, t["means3D"], t["env_scope_mask"], t["colors_precomp"], t["refl_strengths"], t["opacities"], t["scales"], t["rotations"],
+            s.scale_modifier, t["cov3Ds_precomp"], s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, t["sh"],
+            s.sh_degree, s.campos, s.prefiltered, s.debug)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, refl_strengths, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, env_scope_mask):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, refl_strengths, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, env_scope_mask)
+def _split_forward(ret):
+    num_rendered, color, others, radii, geom, binning, img, refl_map, weights = ret
+    return num_rendered, (color, radii, others, refl_map, weights), (geom, binning, img), radii
 
 
-class _RasterizeGaussians(torch.autograd.Function):
-    # reference __init__.py:50-166
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, refl_strengths, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, env_scope_mask):
-        args = (raster_settings.bg, means3D, env_scope_mask, colors_precomp, refl_strengths, opacities, scales, rotations,
-                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix,
-                raster_settings.tanfovx, raster_settings.tanfovy, raster_settings.image_height, raster_settings.image_width, sh,
-                raster_settings.sh_degree, raster_settings.campos, raster_settings.prefiltered, raster_settings.debug)
-        if raster_settings.debug:
-            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
-            try:
-                num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer, refl_strength_map, gaussian_weights = \
-                    _C.rasterize_gaussians(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_fw.dump")
-                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
-                raise ex
-        else:
-            num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer, refl_strength_map, gaussian_weights = \
-                _C.rasterize_gaussians(*args)
-        ctx.raster_settings = raster_settings
-        ctx.num_rendered = num_rendered
-        ctx.save_for_backward(colors_precomp, refl_strengths, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
-                              binningBuffer, imgBuffer)
-        ctx.mark_non_differentiable(radii, gaussian_weights)
-        return color, radii, depth, refl_strength_map, gaussian_weights
-
-    @staticmethod
-    def backward(ctx, grad_out_color, _, grad_depth, grad_out_strength_map, __):
-        num_rendered = ctx.num_rendered
-        raster_settings = ctx.raster_settings
-        colors_precomp, refl_strengths, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
-            ctx.saved_tensors
-        args = (raster_settings.bg, means3D, radii, colors_precomp, refl_strengths, scales, rotations, raster_settings.scale_modifier,
-                cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy,
-                grad_out_color, grad_depth, grad_out_strength_map, sh, raster_settings.sh_degree, raster_settings.campos, geomBuffer,
-                num_rendered, binningBuffer, imgBuffer, raster_settings.debug)
-        if raster_settings.debug:
-            cpu_args = cpu_deep_copy_tuple(args)
-            try:
-                grads_ = _C.rasterize_gaussians_backward(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise ex
-        else:
-            grads_ = _C.rasterize_gaussians_backward(*args)
-        grad_means2D, grad_colors_precomp, grad_refl_strengths, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
-            grad_scales, grad_rotations = grads_
-        # autograd insists on None for inputs that were passed as empty placeholders
-        sink = _C.grad_sink or {}
-        def opt(g, ref, name=None):
-            if name is not None and name in sink:
-                return None   # already written into the caller's sink tensor (see _C.set_grad_sink)
-            return g if (ref is not None and ref.numel() != 0) else None
-        return (opt(grad_means3D, means3D, "means3D"), grad_means2D, opt(grad_sh, sh, "shs"), opt(grad_colors_precomp, colors_precomp),
-                opt(grad_refl_strengths, refl_strengths, "refl_strengths"), (None if "opacities" in sink else grad_opacities),
-                opt(grad_scales, scales, "scales"), opt(grad_rotations, rotations, "rotations"),
-                opt(grad_cov3Ds_precomp, cov3Ds_precomp), None, None)
+def _pack_backward(saved, s, grads, num_rendered, buffers, radii):
+    g_color, _, g_others, g_refl, _ = grads
+    geom, binning, img = buffers
+    return (s.bg, saved["means3D"], radii, saved["colors_precomp"], saved["refl_strengths"], saved["scales"], saved["rotations"],
+            s.scale_modifier, saved["cov3Ds_precomp"], s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, g_color, g_others, g_refl,
+            saved["sh"], s.sh_degree, s.campos, geom, num_rendered, binning, img, s.debug)
 
 
-class GaussianRasterizationSettings(NamedTuple):
-    image_height: int
-    image_width: int
-    tanfovx: float
-    tanfovy: float
-    bg: torch.Tensor
-    scale_modifier: float
-    viewmatrix: torch.Tensor
-    projmatrix: torch.Tensor
-    sh_degree: int
-    campos: torch.Tensor
-    prefiltered: bool
-    debug: bool
+def _grads_of(ret):
+    means2D, colors, refl, opacity, means3D, trans, sh, scales, rotations = ret
+    return dict(means3D=means3D, means2D=means2D, sh=sh, colors_precomp=colors, refl_strengths=refl, opacities=opacity, scales=scales,
+                rotations=rotations, cov3Ds_precomp=trans)
 
 
-class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+def _placeholder(name, device):
+    # the reference substitutes empty CUDA tensors for omitted inputs (__init__.py:210-223)
+    return torch.empty(0, dtype=torch.bool if name == "env_scope_mask" else torch.float32, device=device)
 
-    @staticmethod
-    def set_grad_sink(sink):
-        """Extension (not in the reference): route this rasterizer's parameter gradients into preallocated tensors,
-        see _C.set_grad_sink.  Pass None to restore plain autograd behaviour."""
-        _C.set_grad_sink(sink)
 
-    def markVisible(self, positions):
-        # Mark visible points (based on frustum culling for camera) with a boolean
-        with torch.no_grad():
-            raster_settings = self.raster_settings
-            visible = _C.mark_visible(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
-        return visible
+_VARIANT = Variant(
+    c_module=_C, extra_settings=(),
+    tensors=("means3D", "means2D", "sh", "colors_precomp", "refl_strengths", "opacities", "scales", "rotations", "cov3Ds_precomp",
+             "env_scope_mask"),
+    settings_pos=9,
+    forward_kwargs=(("shs", None), ("colors_precomp", None), ("refl_strengths", None), ("scales", None), ("rotations", None),
+                    ("cov3D_precomp", None), ("env_scope_mask", None)),
+    module_to_apply={"shs": "sh", "cov3D_precomp": "cov3Ds_precomp"},
+    placeholder=_placeholder, pack_forward=_pack_forward, split_forward=_split_forward, nondiff_outputs=(1, 4),
+    saved=("colors_precomp", "refl_strengths", "means3D", "scales", "rotations", "cov3Ds_precomp", "sh"),
+    pack_backward=_pack_backward, grads_of=_grads_of,
+    optional_grads=("sh", "colors_precomp", "refl_strengths", "scales", "rotations", "cov3Ds_precomp", "env_scope_mask"),
+    sinkable={"means3D": "means3D", "sh": "shs", "opacities": "opacities", "scales": "scales", "rotations": "rotations",
+              "refl_strengths": "refl_strengths"},
+    snapshot_on_debug=True)
 
-    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, refl_strengths=None, scales=None, rotations=None,
-                cov3D_precomp=None, env_scope_mask=None):
-        raster_settings = self.raster_settings
-        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
-            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
-        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
-                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        dev = means3D.device
-        empty = lambda: torch.empty(0, dtype=torch.float32, device=dev)
-        if shs is None:
-            shs = empty()
-        if colors_precomp is None:
-            colors_precomp = empty()
-        if scales is None:
-            scales = empty()
-        if rotations is None:
-            rotations = empty()
-        if cov3D_precomp is None:
-            cov3D_precomp = empty()
-        if env_scope_mask is None:
-            env_scope_mask = torch.empty(0, dtype=torch.bool, device=dev)
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, refl_strengths, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings, env_scope_mask)
+GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)
+
+
+def _set_grad_sink(sink):
+    """Extension (not in the reference): route this rasterizer's parameter gradients into preallocated tensors, see
+    _C.set_grad_sink.  Pass None to restore plain autograd behaviour."""
+    _C.set_grad_sink(sink)
+
+
+GaussianRasterizer.set_grad_sink = staticmethod(_set_grad_sink)
