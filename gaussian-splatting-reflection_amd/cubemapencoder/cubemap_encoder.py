@@ -48,42 +48,32 @@ class _Backend:
 
 
 _backend = _Backend()
-
-_interp_to_id = {
-    'nearest': 0,
-    'linear': 1
-}
+_interp_to_id = dict(nearest=0, linear=1)
 
 
 class _cubemap_encode(torch.autograd.Function):
-    # reference cubemap_encoder.py:19-63 (custom_fwd(cast_inputs=float32): inputs are cast to fp32)
+    """(directions [B,3], texture [6,C,L,L], fail_value [C]) -> features [C,B]; gradients for all three.
+    Inputs are brought to contiguous fp32 first (the reference wraps this in custom_fwd(cast_inputs=float32),
+    cubemap_encoder.py:19-63)."""
+
     @staticmethod
     def forward(ctx, inputs, embeddings, fail_value, interpolation, enable_seamless):
-        embeddings = embeddings.float().contiguous()
-        inputs = inputs.float().contiguous()
-        fail_value = fail_value.float().contiguous()
-        C = embeddings.shape[1]
-        L = embeddings.shape[2]
-        B = inputs.shape[0]
-        outputs = torch.empty([C, B], dtype=embeddings.dtype, device=embeddings.device)
-        _backend.cubemap_encode_forward(inputs, embeddings, fail_value, outputs, interpolation, enable_seamless, B, C, L)
-        ctx.params = (int(interpolation), int(enable_seamless))
-        ctx.save_for_backward(inputs, embeddings)
-        return outputs
+        dirs, tex, fail = (x.float().contiguous() for x in (inputs, embeddings, fail_value))
+        B, (C, L) = dirs.shape[0], tex.shape[1:3]
+        out = tex.new_empty((C, B))
+        _backend.cubemap_encode_forward(dirs, tex, fail, out, interpolation, enable_seamless, B, C, L)
+        ctx.mode = (int(interpolation), int(enable_seamless))
+        ctx.save_for_backward(dirs, tex)
+        return out
 
     @staticmethod
     def backward(ctx, grad_outputs):
-        inputs, embeddings = ctx.saved_tensors
-        grad_outputs = grad_outputs.float().contiguous()
-        C = embeddings.shape[1]
-        L = embeddings.shape[2]
-        B = inputs.shape[0]
-        grad_embeddings = torch.zeros_like(embeddings)
-        grad_inputs = torch.empty_like(inputs)
-        grad_fail = torch.zeros([C], dtype=embeddings.dtype, device=embeddings.device)
-        _backend.cubemap_encode_backward(grad_outputs, inputs, embeddings, grad_embeddings, grad_inputs, grad_fail, ctx.params[0],
-                                         ctx.params[1], B, C, L)
-        return grad_inputs, grad_embeddings, grad_fail, None, None
+        dirs, tex = ctx.saved_tensors
+        B, (C, L) = dirs.shape[0], tex.shape[1:3]
+        g_out = grad_outputs.float().contiguous()
+        g_tex, g_dirs, g_fail = torch.zeros_like(tex), torch.empty_like(dirs), tex.new_zeros((C,))
+        _backend.cubemap_encode_backward(g_out, dirs, tex, g_tex, g_dirs, g_fail, ctx.mode[0], ctx.mode[1], B, C, L)
+        return g_dirs, g_tex, g_fail, None, None
 
 
 cubemap_encode = _cubemap_encode.apply
@@ -92,96 +82,87 @@ cubemap_encode = _cubemap_encode.apply
 def _adjust_sharpness(img, factor):
     """torchvision.transforms.functional.adjust_sharpness restated in plain torch (torchvision is not a
     dependency here): blend with a 3x3 smoothed copy (kernel [[1,1,1],[1,5,1],[1,1,1]]/13), borders kept."""
-    if img.shape[-1] <= 2 or img.shape[-2] <= 2:
+    if min(img.shape[-2:]) <= 2:
         return img
-    k = torch.ones(3, 3, dtype=img.dtype, device=img.device)
-    k[1, 1] = 5.0
-    k = (k / k.sum()).expand(img.shape[-3], 1, 3, 3)
-    x = img.reshape(-1, img.shape[-3], img.shape[-2], img.shape[-1])
-    blurred = nn.functional.conv2d(x, k, groups=x.shape[1])
-    degenerate = x.clone()
-    degenerate[..., 1:-1, 1:-1] = blurred
-    out = (factor * x + (1.0 - factor) * degenerate).clamp(0, 1)
-    return out.reshape(img.shape)
+    chans = img.shape[-3]
+    kernel = torch.ones(3, 3, dtype=img.dtype, device=img.device)
+    kernel[1, 1] = 5.0
+    kernel = (kernel / kernel.sum()).expand(chans, 1, 3, 3)
+    batch = img.reshape(-1, chans, *img.shape[-2:])
+    smooth = batch.clone()
+    smooth[..., 1:-1, 1:-1] = nn.functional.conv2d(batch, kernel, groups=chans)
+    return (factor * batch + (1.0 - factor) * smooth).clamp(0, 1).reshape(img.shape)
 
 
-class CubemapEncoder(nn.Module):
-    # reference cubemap_encoder.py:81-123
-    def __init__(self, output_dim=6, resolution=256, interpolation='linear'):
-        super().__init__()
-        self.input_dim = 3
-        self.resolution = resolution
-        self.output_dim = output_dim
+class _CubeLookup(nn.Module):
+    """What both encoders share: direction input, interpolation mode, seamless edge handling."""
+    input_dim = 3
+    seamless = 1
+
+    def _set_mode(self, interpolation):
         self.interpolation = interpolation
         self.interp_id = _interp_to_id[interpolation]
-        self.seamless = 1
-        self.params = nn.ParameterDict({
-            'Cubemap_texture': nn.Parameter(torch.rand(6, self.output_dim, resolution, resolution) - 0.5),
-            'Cubemap_failv': nn.Parameter(torch.zeros(self.output_dim))
-        })
-        self.n_elems = 6 * self.output_dim * resolution * resolution + self.output_dim
+
+    def _lookup(self, dirs, texture, fail_value):
+        return cubemap_encode(dirs, texture, fail_value, self.interp_id, self.seamless)
+
+
+class CubemapEncoder(_CubeLookup):
+    """One 6 x C x L x L texture + a C-vector returned for the zero direction (reference cubemap_encoder.py:81-123).
+    `params` keeps the reference's ParameterDict keys because checkpoints (`.map` files) are its state dict."""
+
+    def __init__(self, output_dim=6, resolution=256, interpolation='linear'):
+        super().__init__()
+        self.output_dim, self.resolution = output_dim, resolution
+        self._set_mode(interpolation)
+        self.params = nn.ParameterDict(dict(Cubemap_texture=nn.Parameter(torch.rand(6, output_dim, resolution, resolution) - 0.5),
+                                            Cubemap_failv=nn.Parameter(torch.zeros(output_dim))))
+
+    @property
+    def n_elems(self):
+        return 6 * self.output_dim * self.resolution ** 2 + self.output_dim
 
     def __repr__(self):
         return (f"CubemapEncoder: input_dim={self.input_dim} output_dim={self.output_dim} resolution={self.resolution} -> {self.n_elems} "
                 f"interpolation={self.interpolation} seamless={self.seamless}")
 
-    def resize(self, new_resolution):
-        self.resolution = new_resolution
-        self.params['Cubemap_texture'] = nn.functional.interpolate(self.params['Cubemap_texture'], size=(new_resolution, new_resolution),
-                                                                   mode='bicubic', align_corners=True)
-        self.n_elems = 6 * self.output_dim * self.resolution * self.resolution + self.output_dim
-
-    def filter(self, activation, inverse_activation, factor=2.0):
-        textures = self.params['Cubemap_texture']
-        textures = activation(textures)
-        textures = _adjust_sharpness(textures, factor)
-        textures = torch.clamp(textures, min=1e-3, max=1 - 1e-3)
-        textures = inverse_activation(textures)
-        self.params['Cubemap_texture'] = textures
-
     def set_textures(self, textures):
         self.resolution = textures.shape[2]
         self.params['Cubemap_texture'] = nn.Parameter(textures)
-        self.n_elems = 6 * self.output_dim * self.resolution * self.resolution + self.output_dim
+
+    def resize(self, new_resolution):
+        up = nn.functional.interpolate(self.params['Cubemap_texture'], size=(new_resolution,) * 2, mode='bicubic', align_corners=True)
+        self.resolution = new_resolution
+        self.params['Cubemap_texture'] = up
+
+    def filter(self, activation, inverse_activation, factor=2.0):
+        sharpened = _adjust_sharpness(activation(self.params['Cubemap_texture']), factor)
+        self.params['Cubemap_texture'] = inverse_activation(sharpened.clamp(min=1e-3, max=1 - 1e-3))
 
     def forward(self, inputs):
-        outputs = cubemap_encode(inputs, self.params['Cubemap_texture'], self.params['Cubemap_failv'], self.interp_id, self.seamless)
-        return outputs.permute(1, 0)  # CxN -> NxC
+        return self._lookup(inputs, self.params['Cubemap_texture'], self.params['Cubemap_failv']).permute(1, 0)   # CxN -> NxC
 
 
-class MipCubemapEncoder(nn.Module):
-    # reference cubemap_encoder.py:126-178 (never instantiated by the reference; kept for API completeness)
+class MipCubemapEncoder(_CubeLookup):
+    """A pyramid of cubemaps whose features are concatenated or summed (reference cubemap_encoder.py:126-178; the
+    reference never instantiates it, it is here for API completeness)."""
+
     def __init__(self, num_levels=4, level_dim=6, per_level_scale=4, base_resolution=4, interpolation='linear', concat=True):
         super().__init__()
-        self.input_dim = 3
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.base_resolution = base_resolution
-        self.concat = concat
+        self.num_levels, self.level_dim, self.per_level_scale = num_levels, level_dim, per_level_scale
+        self.base_resolution, self.concat = base_resolution, concat
         self.output_dim = num_levels * level_dim if concat else level_dim
-        self.interpolation = interpolation
-        self.interp_id = _interp_to_id[interpolation]
-        self.seamless = 1
-        params_list = []
-        L = float(base_resolution)
-        n_elems = 0
-        for _ in range(num_levels):
-            iL = int(np.ceil(L))
-            params_list.append(nn.Parameter(torch.empty(6, self.level_dim, iL, iL)))
-            n_elems += 6 * self.level_dim * iL * iL
-            L = L * per_level_scale
-        self.params_list = nn.ParameterList(params_list)
-        self.fail_value = nn.Parameter(torch.zeros(self.level_dim))
-        self.n_elems = n_elems + self.level_dim
+        self._set_mode(interpolation)
+        sizes = [int(np.ceil(float(base_resolution) * per_level_scale ** lvl)) for lvl in range(num_levels)]
+        self.params_list = nn.ParameterList([nn.Parameter(torch.empty(6, level_dim, n, n)) for n in sizes])
+        self.fail_value = nn.Parameter(torch.zeros(level_dim))
+        self.n_elems = sum(6 * level_dim * n * n for n in sizes) + level_dim
         self.reset_parameters()
 
-    def reset_parameters(self):
-        std = 1e-4
-        for ii in range(self.num_levels):
-            self.params_list[ii].data.uniform_(-std, std)
+    def reset_parameters(self, std=1e-4):
+        for tex in self.params_list:
+            tex.data.uniform_(-std, std)
 
     def forward(self, inputs):
-        outputs = [cubemap_encode(inputs, self.params_list[ii], self.fail_value, self.interp_id, self.seamless) for ii in range(self.num_levels)]
-        outputs = torch.cat(outputs, dim=0) if self.concat else sum(outputs)
-        return outputs.permute(1, 0)
+        levels = [self._lookup(inputs, tex, self.fail_value) for tex in self.params_list]
+        return (torch.cat(levels, dim=0) if self.concat else sum(levels)).permute(1, 0)
