@@ -5,6 +5,7 @@
 #include "gsr_internal.hpp"
 #include <cstdarg>
 #include <string>
+#include <initializer_list>
 #include <vector>
 #include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -286,6 +287,14 @@ __global__ void __launch_bounds__(256) widen_clamped_kernel(int P, const uint8_t
 	out[3 * idx + 1] = (b >> 1) & 1;
 	out[3 * idx + 2] = (b >> 2) & 1;
 }
+// Gather up to 9 floats per record by explicit position (debug views of records whose fields are not contiguous).
+struct RecPick { int n; int pos[9]; };
+__global__ void __launch_bounds__(256) pick_rec_kernel(int P, const float* __restrict__ rec, int stride, RecPick pick, float* __restrict__ out) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P * pick.n) return;
+	const int idx = i / pick.n, k = i % pick.n;
+	out[i] = rec[(size_t)idx * stride + pick.pos[k]];
+}
 // Gather `nf` floats starting at float `first` of each record (stride rec_f4*4 floats) into a dense [P, nf] array.
 __global__ void __launch_bounds__(256) gather_rec_kernel(int P, const float* __restrict__ rec, int stride, int first, int nf,
                                                          float* __restrict__ out) {
@@ -377,11 +386,22 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 		GSR_LAUNCH_CHECK(0, stream);
 		return 0;
 	}
-	if (n == "rgb") return gather(variant == 0 ? 15 : 6, 3);
+	auto pick = [&](std::initializer_list<int> pos) -> int {
+		if (P == 0) return 0;
+		RecPick pk;
+		pk.n = (int)pos.size();
+		int i = 0;
+		for (int v : pos) pk.pos[i++] = v;
+		pick_rec_kernel<<<(P * pk.n + 255) / 256, 256, 0, stream>>>(P, (const float*)g.rec, stride, pk, (float*)dst);
+		GSR_LAUNCH_CHECK(0, stream);
+		return 0;
+	};
+	// variant S record: {x, y | Tu.x, Tv.x} {Tu.y, Tv.y | Tu.z, Tv.z} {Tw.x, Tw.y | Tw.z, opacity} {n.x, n.y | n.z, refl} {r, g | b, mask}
+	if (n == "rgb") return variant == 0 ? gather(16, 3) : gather(6, 3);
 	if (n == "geom4") {  // G: conic.xyz + opacity ; S: normal.xyz + opacity
-		return gather(variant == 0 ? 11 : 2, 4);
+		return variant == 0 ? pick({12, 13, 14, 11}) : gather(2, 4);
 	}
-	if (n == "transMat" && variant == 0) return gather(2, 9);
+	if (n == "transMat" && variant == 0) return pick({2, 4, 6, 3, 5, 7, 8, 9, 10});
 	if (n == "cov3D" && variant == 1) return d2d(g.aux, (size_t)P * 6 * 4);
 	if (n == "point_list") return d2d(b.point_list, (size_t)R * 4);
 	if (n == "keys") {   // reference-format sorted keys, rebuilt (the product path sorts tile ids only)

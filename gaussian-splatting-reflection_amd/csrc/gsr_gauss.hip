@@ -688,7 +688,7 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
 	if (R < 0) return R;
 
-	const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 	{
 		StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
 		if (out_invdepth)
@@ -732,7 +732,7 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * G_ACC_F * sizeof(float), stream));
 	if (R > 0) {
-		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		{
 			StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 			if (dL_invdepths)

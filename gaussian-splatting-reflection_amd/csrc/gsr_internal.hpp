@@ -190,6 +190,50 @@ __device__ __forceinline__ void row_sum4(float* z) {
 	asm volatile("s_nop 1\n\t" GSR_DPP4(GSR_SHR1) GSR_DPP4(GSR_SHR2) GSR_DPP4(GSR_SHR4) GSR_DPP4(GSR_SHR8)
 	             : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
 }
+// ---- in-row packed reduction (exchange-type DPP only; measured on MI355X: v_permlane32/16_swap cost ~4x a DPP add, so
+// the swap-based fold4 above is the SLOWER way to pack on this part — tests/ablate notes in DESIGN.md).
+// Four values (a, b, c, d) per call are reduced over each 16-lane row: level 1 pairs lane i with 15-i (row_mirror) and
+// keeps a in lanes 0-7 / b in lanes 8-15, level 2 pairs i with 7-i inside each half (row_half_mirror) and keeps the first
+// pair's result in lanes 0-3 of each half / the second pair's in lanes 4-7; two quad_perm adds finish the row sum.
+// Result: every lane of quad q of a row holds the ROW total of value {a, c, b, d}[q].  3+3+3+2 = 11 instructions per 4
+// values and per row; the four row totals are combined by the caller (LDS atomics).
+#define GSR_DPPX(CTRL, dst, dppsrc, src) "v_add_f32_dpp %" #dst ", %" #dppsrc ", %" #src " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define GSR_Q1(CTRL, i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+// NG groups of four values v[4g..4g+3] -> z[g]; all DPP instructions of one level sit in one asm statement (one s_nop
+// for the VALU-write -> DPP-read hazard per level instead of one per group).
+template <int NG>
+__device__ __forceinline__ void row_reduce_groups(const float* v, float* z, bool up8, bool up4) {
+	float p[NG], q[NG];
+#pragma unroll
+	for (int g = 0; g < NG; g++) {
+		const float a = v[4 * g], b = v[4 * g + 1], c = v[4 * g + 2], d = v[4 * g + 3];
+		const float k1 = up8 ? b : a, s1 = up8 ? a : b, k2 = up8 ? d : c, s2 = up8 ? c : d;
+		// level 1 (one asm per group keeps the operand count within asm limits; the leading s_nop only matters once)
+		asm volatile("s_nop 1\n\t" GSR_DPPX("row_mirror", 0, 2, 3) GSR_DPPX("row_mirror", 1, 4, 5)
+		             : "=&v"(p[g]), "=&v"(q[g]) : "v"(s1), "v"(k1), "v"(s2), "v"(k2));
+	}
+#pragma unroll
+	for (int g = 0; g < NG; g++) {
+		const float k3 = up4 ? q[g] : p[g], s3 = up4 ? p[g] : q[g];
+		asm volatile("s_nop 1\n\t" GSR_DPPX("row_half_mirror", 0, 1, 2) : "=&v"(z[g]) : "v"(s3), "v"(k3));
+	}
+}
+// levels 3 and 4 (interleaved so that no DPP reads a register written < 2 instructions before)
+__device__ __forceinline__ void quad_sum5(float* z) {
+#define GSR_Q5(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3) GSR_Q1(CTRL, 4)
+	asm volatile("s_nop 1\n\t" GSR_Q5("quad_perm:[2,3,0,1]") GSR_Q5("quad_perm:[1,0,3,2]")
+	             : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]));
+}
+__device__ __forceinline__ void quad_sum4(float* z) {
+#define GSR_Q4(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3)
+	asm volatile("s_nop 1\n\t" GSR_Q4("quad_perm:[2,3,0,1]") GSR_Q4("quad_perm:[1,0,3,2]") : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+}
+// which of the four values of a row_reduce4 call quad q of a row ends up with
+__device__ __forceinline__ int row_reduce_slot(int lane) {
+	const int q = (lane >> 2) & 3;          // quads 0,1,2,3 hold a, c, b, d
+	return ((q & 1) << 1) | (q >> 1);
+}
+
 // slot (0..3) inside a folded group that the lane's row holds: rows 0,1,2,3 carry values 0,2,1,3
 __device__ __forceinline__ int fold_slot(int lane) {
 	const int row = lane >> 4;
@@ -278,14 +322,22 @@ __device__ __forceinline__ bool cull_hit(const float4 c0, const float4 c1, float
 	return hit;
 }
 
-// XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so
-// give each XCD a contiguous band of tiles (neighbouring tiles gather the same Gaussian records and
-// then hit the same L2).  Pure performance; any mapping is correct.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles) {
-	const uint32_t nx = 8;
-	const uint32_t per = (ntiles + nx - 1) / nx;
-	uint32_t t = (bid % nx) * per + bid / nx;
-	return t;  // may be >= ntiles for the ragged tail: caller launches per*8 blocks and checks
+// XCD-aware unit order.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2).
+// Units that are neighbours in the image gather the same Gaussian records, so they should share an XCD; but giving each
+// XCD one contiguous band of the image (the first version) ties its load to the local density of the scene — the bands
+// at the top and bottom of the synthetic C3 view hold far fewer instances than the middle ones and their XCDs idled.
+// Chunks of XCD_CHUNK consecutive units are therefore dealt round-robin: locality inside a chunk, balance across the image.
+// Pure performance; any bijective mapping is correct.  The caller launches a multiple of 8 * XCD_CHUNK workgroups and
+// drops units >= nunits.
+#define XCD_CHUNK 64
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nunits) {
+	(void)nunits;
+	const uint32_t xcd = bid & 7u, j = bid >> 3;
+	return ((j / XCD_CHUNK) * 8u + xcd) * XCD_CHUNK + (j % XCD_CHUNK);
+}
+__host__ __device__ __forceinline__ uint32_t xcd_grid(uint32_t nunits) {
+	const uint32_t g = 8u * XCD_CHUNK;
+	return (nunits + g - 1) / g * g;
 }
 
 }  // namespace gsr

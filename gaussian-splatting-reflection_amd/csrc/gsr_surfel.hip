@@ -219,47 +219,80 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 		g.bbox[2 * idx + 1] = c1;
 	}
 	float4* rec = g.rec + (size_t)idx * S_REC_F4;
-	rec[0] = make_float4(pxi, pyi, T.m[0][0], T.m[0][1]);
-	rec[1] = make_float4(T.m[0][2], T.m[1][0], T.m[1][1], T.m[1][2]);
-	rec[2] = make_float4(T.m[2][0], T.m[2][1], T.m[2][2], normal.x);
-	rec[3] = make_float4(normal.y, normal.z, opacities[idx], cr);
-	rec[4] = make_float4(cg, cb, refl[idx], maskv);
+	// Render record, laid out in even-aligned PAIRS so that the tile kernels can feed them to packed fp32 instructions
+	// (v_pk_mul/add/fma_f32 take a 64-bit aligned SGPR pair) straight from the s_load destination:
+	//   {x, y | Tu.x, Tv.x} {Tu.y, Tv.y | Tu.z, Tv.z} {Tw.x, Tw.y | Tw.z, opacity} {n.x, n.y | n.z, refl} {r, g | b, mask}
+	rec[0] = make_float4(pxi, pyi, T.m[0][0], T.m[1][0]);
+	rec[1] = make_float4(T.m[0][1], T.m[1][1], T.m[0][2], T.m[1][2]);
+	rec[2] = make_float4(T.m[2][0], T.m[2][1], T.m[2][2], opacities[idx]);
+	rec[3] = make_float4(normal.x, normal.y, normal.z, refl[idx]);
+	rec[4] = make_float4(cr, cg, cb, maskv);
 	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
 }
 
 // Ray-splat intersection and falloff for one (pixel, surfel) pair, shared by the forward and backward
 // tile kernels (DSR forward.cu:362-410, backward.cu:292-336).  EPS is the `unstable` threshold: 1e-4 in
 // the forward, 1e-6 in the backward — a quirk of the reference that is reproduced on purpose.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
+// X, Y, Z hold the x, y, z components of the two plane vectors as pairs: X = (k.x, l.x) etc.
 struct SurfelPair {
-	float kx, ky, kz, lx, ly, lz, pz, inv_pz, sx, sy, dx, dy, rho3d, rho2d, depth, G, alpha;
+	v2f X, Y, Z, s, d;
+	float pz, inv_pz, rho3d, rho2d, depth, G, alpha;
+};
+// The five float4 of a render record by meaning (layout: see surfel_preprocess_kernel).
+struct SurfelRec {
+	float4 r0, r1, r2, r3, r4;
+	__device__ __forceinline__ v2f xy() const { return mk2(r0.x, r0.y); }
+	__device__ __forceinline__ v2f TuvX() const { return mk2(r0.z, r0.w); }
+	__device__ __forceinline__ v2f TuvY() const { return mk2(r1.x, r1.y); }
+	__device__ __forceinline__ v2f TuvZ() const { return mk2(r1.z, r1.w); }
+	__device__ __forceinline__ v2f Twxy() const { return mk2(r2.x, r2.y); }
+	__device__ __forceinline__ float Twz() const { return r2.z; }
+	__device__ __forceinline__ float opac() const { return r2.w; }
+	__device__ __forceinline__ v2f nxy() const { return mk2(r3.x, r3.y); }
+	__device__ __forceinline__ float nz() const { return r3.z; }
+	__device__ __forceinline__ float refl() const { return r3.w; }
+	__device__ __forceinline__ v2f rg() const { return mk2(r4.x, r4.y); }
+	__device__ __forceinline__ float b() const { return r4.z; }
+	__device__ __forceinline__ float mask() const { return r4.w; }
 };
 template <bool FWD>
-__device__ __forceinline__ bool surfel_pair(const float4 r0, const float4 r1, const float4 r2, float opac, float pixx, float pixy, SurfelPair& o) {
+__device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, float pixy, SurfelPair& o) {
 #pragma clang fp contract(off)
-	const float Tux = r0.z, Tuy = r0.w, Tuz = r1.x, Tvx = r1.y, Tvy = r1.z, Tvz = r1.w, Twx = r2.x, Twy = r2.y, Twz = r2.z;
 	// Plain IEEE mul/sub in the reference's textual order (contraction off): the plane/plane cross product
 	// cancels catastrophically in fp32 (|k|,|l| ~ pixel coordinate x T), so evaluation order changes s by
 	// ~1e-4 relative.  Matching the order makes the HIP path agree with the oracle to rounding of exp().
-	o.kx = pixx * Twx - Tux; o.ky = pixx * Twy - Tuy; o.kz = pixx * Twz - Tuz;
-	o.lx = pixy * Twx - Tvx; o.ly = pixy * Twy - Tvy; o.lz = pixy * Twz - Tvz;
-	const float ppx = o.ky * o.lz - o.kz * o.ly;
-	const float ppy = o.kz * o.lx - o.kx * o.lz;
-	o.pz = o.kx * o.ly - o.ky * o.lx;
+	// Written on <2 x float>: each line is ONE packed instruction doing the k- and the l-side (or the x- and the y-side)
+	// of the reference's arithmetic with the same individually rounded operations.
+	const v2f pix = mk2(pixx, pixy);
+	const v2f Tw = R.Twxy();
+	o.X = pix * Tw.x - R.TuvX();          // k.x = pix.x*Tw.x - Tu.x | l.x = pix.y*Tw.x - Tv.x
+	o.Y = pix * Tw.y - R.TuvY();
+	o.Z = pix * R.Twz() - R.TuvZ();
+	const v2f a = o.Y * o.Z.yx;           // (k.y*l.z, l.y*k.z)
+	const v2f b = o.Z * o.X.yx;           // (k.z*l.x, l.z*k.x)
+	const v2f c = o.X * o.Y.yx;           // (k.x*l.y, l.x*k.y)
+	const v2f pp = mk2(a.x - a.y, b.x - b.y);
+	o.pz = c.x - c.y;
 	// straight-line code (selects, no early returns): fewer exec-mask branches in the hot loop.  (Evaluating two list
 	// entries per iteration so that the scheduler can interleave two of these chains was tried and measured 3 % slower.)
 	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
 	o.inv_pz = div_nr(1.0f, unstable ? 1.0f : o.pz);  // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale)
-	o.sx = unstable ? 0.f : ppx * o.inv_pz;
-	o.sy = unstable ? 0.f : ppy * o.inv_pz;
-	o.rho3d = unstable ? 1e8f : (o.sx * o.sx + o.sy * o.sy);
-	o.dx = r0.x - pixx;
-	o.dy = r0.y - pixy;
-	o.rho2d = S_FILTER_INV_SQ * (o.dx * o.dx + o.dy * o.dy);
+	const v2f sr = pp * o.inv_pz;
+	o.s = mk2(unstable ? 0.f : sr.x, unstable ? 0.f : sr.y);
+	const v2f s2 = o.s * o.s;
+	o.rho3d = unstable ? 1e8f : (s2.x + s2.y);
+	o.d = R.xy() - pix;
+	const v2f d2 = o.d * o.d;
+	o.rho2d = S_FILTER_INV_SQ * (d2.x + d2.y);
 	const float rho = fminf(o.rho3d, o.rho2d);
-	o.depth = (o.sx * Twx + o.sy * Twy) + Twz;
+	const v2f st = o.s * Tw;
+	o.depth = (st.x + st.y) + R.Twz();
 	const float power = -0.5f * rho;
 	o.G = exp_neg(power);  // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by the backward
-	o.alpha = fminf(0.99f, opac * o.G);
+	o.alpha = fminf(0.99f, R.opac() * o.G);
 	// reference order of the tests: depth < near, power > 0, alpha < 1/255 (DSR forward.cu:394-410)
 	return !(o.depth < S_NEAR) && !(power > 0.0f) && !(o.alpha < 1.0f / 255.0f);
 }
@@ -278,7 +311,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                               float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, contiguous per XCD
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, chunked round-robin over the XCDs
 	if (unit >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -299,8 +332,9 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 	bool done = !inside;
 	float T = 1.0f;
 	uint32_t last_contributor = 0;
-	float C0 = 0, C1 = 0, C2 = 0, RS = 0, mask = 0;
-	float N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+	// accumulators paired like the record: (r, g), b | (n.x, n.y), (n.z, refl) | (depth, m)
+	v2f Crg = mk2(0.f, 0.f), Nxy = mk2(0.f, 0.f), NzR = mk2(0.f, 0.f), DM = mk2(0.f, 0.f);
+	float C2 = 0, mask = 0, M2 = 0, distortion = 0, median_depth = 0;
 	float median_contributor = -1.0f;
 
 	for (int base = 0; base < count; base += S_WBATCH) {
@@ -330,7 +364,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		// right after the ray-splat evaluation of the current one; with a single rotating buffer the compiler copies the 20
 		// SGPRs twice per pair (~25 of the ~60 scalar instructions per pair, and SALU issue is as scarce as VALU issue).
 		unsigned long long touched = 0ull;
-		struct Rec { float4 r0, r1, r2, r3, r4; };
+		using Rec = SurfelRec;
 		auto fetch = [&](int k) -> Rec {
 			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
@@ -341,7 +375,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 			// straight-line for all 64 lanes: a lane whose pair does not contribute blends with weight 0 (the identity of
 			// every accumulator) instead of sitting out in an exec-mask region
 			SurfelPair o;
-			const bool pair_ok = surfel_pair<true>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			const bool pair_ok = surfel_pair<true>(R, pixx, pixy, o);
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
 			__builtin_amdgcn_sched_barrier(0);
@@ -355,18 +389,18 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 				const float depth = ok ? o.depth : 1.0f;
 				const float A = 1 - T;
 				const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(depth));
-				const float mw = m * w;
-				distortion += (m * m * A + M2 - 2 * m * M1) * w;
-				Dp += depth * w;
-				M1 += mw;
-				M2 += m * mw;
+				const v2f w2 = mk2(w, w);
+				distortion += (m * m * A + M2 - 2 * m * DM.y) * w;
+				M2 += m * (m * w);
+				DM = __builtin_elementwise_fma(mk2(depth, m), w2, DM);        // depth sum, M1
 				const bool med = ok && T > 0.5f;
 				median_depth = med ? depth : median_depth;
 				median_contributor = med ? (float)contributor : median_contributor;
-				N0 = fmaf(R.r2.w, w, N0); N1 = fmaf(R.r3.x, w, N1); N2 = fmaf(R.r3.y, w, N2);
-				C0 = fmaf(R.r3.w, w, C0); C1 = fmaf(R.r4.x, w, C1); C2 = fmaf(R.r4.y, w, C2);
-				RS = fmaf(R.r4.z, w, RS);
-				mask = (ok && R.r4.w != 0.f) ? 1.0f : mask;
+				Nxy = __builtin_elementwise_fma(R.nxy(), w2, Nxy);
+				NzR = __builtin_elementwise_fma(mk2(R.nz(), R.refl()), w2, NzR);
+				Crg = __builtin_elementwise_fma(R.rg(), w2, Crg);
+				C2 = fmaf(R.b(), w, C2);
+				mask = (ok && R.mask() != 0.f) ? 1.0f : mask;
 				T = ok ? test_T : T;
 				last_contributor = ok ? contributor : last_contributor;
 				// gaussian_weights (forward.cu:458-459): max over the wave's pixels; merged across waves by atomicMax
@@ -395,19 +429,19 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		const size_t HW = (size_t)H * W;
 		const size_t pix = (size_t)W * py + px;
 		final_T[pix] = T;
-		final_T[HW + pix] = M1;
+		final_T[HW + pix] = DM.y;
 		final_T[2 * HW + pix] = M2;
 		n_contrib[pix] = last_contributor;
 		n_contrib[HW + pix] = (uint32_t)median_contributor;  // v_cvt_u32_f32 saturates: -1 -> 0, as cvt.rzi.u32.f32 does
-		out_color[pix] = C0 + T * bg[0];
-		out_color[HW + pix] = C1 + T * bg[1];
+		out_color[pix] = Crg.x + T * bg[0];
+		out_color[HW + pix] = Crg.y + T * bg[1];
 		out_color[2 * HW + pix] = C2 + T * bg[2];
-		out_refl[pix] = RS;
-		out_others[0 * HW + pix] = Dp;
+		out_refl[pix] = NzR.y;
+		out_others[0 * HW + pix] = DM.x;
 		out_others[1 * HW + pix] = 1 - T;
-		out_others[2 * HW + pix] = N0;
-		out_others[3 * HW + pix] = N1;
-		out_others[4 * HW + pix] = N2;
+		out_others[2 * HW + pix] = Nxy.x;
+		out_others[3 * HW + pix] = Nxy.y;
+		out_others[4 * HW + pix] = NzR.x;
 		out_others[5 * HW + pix] = median_depth;
 		out_others[6 * HW + pix] = distortion;
 		out_others[7 * HW + pix] = mask;
@@ -420,7 +454,9 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 struct SurfelBwdPix {
 	float T, T_final, last_dL_dT, bg_dot_dpixel;
 	int last_contributor, median_contributor;
-	float dp0, dp1, dp2, dr, dL_ddepth, dL_daccum, dnx, dny, dnz, dL_dmedian_depth;
+	v2f dp01, dn01, dnzr;          // upstream gradients paired like the record: (r, g), (n.x, n.y), (n.z, refl)
+	v2f pixm;                      // (pix.x, -pix.y)
+	float dp2, dL_ddepth, dL_daccum, dL_dmedian_depth;
 	float FD2r, FAr, FDr;          // final_D2, final_A, final_D times dL_dreg
 	float A, Dprev, last_alpha;    // blended <attributes, upstream grads> behind this pixel's current position
 };
@@ -432,15 +468,16 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 	s.T = s.T_final;
 	s.last_contributor = inside ? (int)n_contrib[pix] : 0;
 	s.median_contributor = inside ? (int)n_contrib[HW + pix] : 0;
-	s.dp0 = s.dp1 = s.dp2 = s.dr = 0.f;
-	s.dL_ddepth = s.dL_daccum = s.dnx = s.dny = s.dnz = s.dL_dmedian_depth = 0.f;
+	s.dp01 = s.dn01 = s.dnzr = mk2(0.f, 0.f);
+	s.dp2 = s.dL_ddepth = s.dL_daccum = s.dL_dmedian_depth = 0.f;
 	float dL_dreg = 0.f;
 	if (inside) {
-		s.dp0 = dL_dpixels[pix]; s.dp1 = dL_dpixels[HW + pix]; s.dp2 = dL_dpixels[2 * HW + pix];
-		s.dr = dL_drefl_map[pix];
+		s.dp01 = mk2(dL_dpixels[pix], dL_dpixels[HW + pix]);
+		s.dp2 = dL_dpixels[2 * HW + pix];
 		s.dL_ddepth = dL_depths[0 * HW + pix];
 		s.dL_daccum = dL_depths[1 * HW + pix];
-		s.dnx = dL_depths[2 * HW + pix]; s.dny = dL_depths[3 * HW + pix]; s.dnz = dL_depths[4 * HW + pix];
+		s.dn01 = mk2(dL_depths[2 * HW + pix], dL_depths[3 * HW + pix]);
+		s.dnzr = mk2(dL_depths[4 * HW + pix], dL_drefl_map[pix]);
 		s.dL_dmedian_depth = dL_depths[5 * HW + pix];
 		dL_dreg = dL_depths[6 * HW + pix];
 	}
@@ -449,7 +486,7 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 	s.FAr = (1 - s.T_final) * dL_dreg;
 	s.last_dL_dT = 0;
 	s.A = s.Dprev = s.last_alpha = 0.f;
-	s.bg_dot_dpixel = bg[0] * s.dp0 + bg[1] * s.dp1 + bg[2] * s.dp2;
+	s.bg_dot_dpixel = bg[0] * s.dp01.x + bg[1] * s.dp01.y + bg[2] * s.dp2;
 }
 // One (pixel, surfel) pair of the back-to-front recursion (DSR backward.cu:338-467): advances the per-pixel state and
 // writes the 19 gradient contributions (slots SA_*) into v.  Straight-line for all 64 lanes:
@@ -461,30 +498,34 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 //     linear, so ONE scalar recurrence A over D = <attributes, upstream grads> replaces the nine (same value up
 //     to summation order);
 //   * 1/(1-alpha), 1/depth and 1/p.z are formed once (Newton-refined v_rcp) and multiplied through.
-__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, bool ok, const float4 r2, const float4 r3,
-                                                const float4 r4, int contributor, float pixx, float pixy, float* v) {
+__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, bool ok, const SurfelRec& R, int contributor, float* v) {
 	const float alpha = ok ? o.alpha : 0.f;
 	const float c_d = ok ? o.depth : 1.0f;
 	// a rejected pair may carry inf/NaN here (s overflows when the ray grazes the splat plane); 0 * that must stay 0
-	const float G = ok ? o.G : 0.f, sx = ok ? o.sx : 0.f, sy = ok ? o.sy : 0.f;
-	const float Twx = r2.x, Twy = r2.y;
+	const float G = ok ? o.G : 0.f;
+	const v2f sxy = mk2(ok ? o.s.x : 0.f, ok ? o.s.y : 0.f);
 	const float inv_1ma = div_nr(1.0f, 1.f - alpha);
 	s.T *= inv_1ma;
 	const float T = s.T;
 	const float w = alpha * T;
-	const float D = r3.w * s.dp0 + r4.x * s.dp1 + r4.y * s.dp2 + r4.z * s.dr + c_d * s.dL_ddepth + s.dL_daccum
-	              + r2.w * s.dnx + r3.x * s.dny + r3.y * s.dnz;
+	const v2f w2 = mk2(w, w);
+	// D = <attributes of this surfel, upstream gradients>, pairs first
+	v2f Dv = R.rg() * s.dp01;
+	Dv = __builtin_elementwise_fma(R.nxy(), s.dn01, Dv);
+	Dv = __builtin_elementwise_fma(mk2(R.nz(), R.refl()), s.dnzr, Dv);
+	const float D = (Dv.x + Dv.y) + R.b() * s.dp2 + c_d * s.dL_ddepth + s.dL_daccum;
 	s.A = s.last_alpha * s.Dprev + (1.f - s.last_alpha) * s.A;
 	s.Dprev = D;
 	s.last_alpha = alpha;
 	float dL_dalpha = D - s.A;
-	v[SA_COLOR + 0] = w * s.dp0;
-	v[SA_COLOR + 1] = w * s.dp1;
+	const v2f vc = w2 * s.dp01, vn = w2 * s.dn01, vz = w2 * s.dnzr;
+	v[SA_COLOR + 0] = vc.x;
+	v[SA_COLOR + 1] = vc.y;
 	v[SA_COLOR + 2] = w * s.dp2;
-	v[SA_REFL] = w * s.dr;
-	v[SA_NORMAL + 0] = w * s.dnx;
-	v[SA_NORMAL + 1] = w * s.dny;
-	v[SA_NORMAL + 2] = w * s.dnz;
+	v[SA_REFL] = vz.y;
+	v[SA_NORMAL + 0] = vn.x;
+	v[SA_NORMAL + 1] = vn.y;
+	v[SA_NORMAL + 2] = vz.x;
 	// distortion regulariser
 	const float rc = div_nr(1.0f, c_d);
 	const float m_d = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * rc);
@@ -499,23 +540,35 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 	dL_dalpha -= s.T_final * inv_1ma * s.bg_dot_dpixel;
 	dL_dalpha = ok ? dL_dalpha : 0.f;
 	dL_dz = ok ? dL_dz : 0.f;
-	const float nG = -G * (r3.z * dL_dalpha);   // dL_dG * -G
+	const float nG = -G * (R.opac() * dL_dalpha);   // dL_dG * -G
 	const bool use3d = o.rho3d <= o.rho2d;
-	const float dL_dsx = use3d ? nG * sx + dL_dz * Twx : 0.f;
-	const float dL_dsy = use3d ? nG * sy + dL_dz * Twy : 0.f;
-	const float dpx = dL_dsx * o.inv_pz, dpy = dL_dsy * o.inv_pz, dpz = -(dpx * sx + dpy * sy);
-	// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k); the T rows receive -dL_dk, -dL_dl and pix.x*dL_dk + pix.y*dL_dl.
-	// nk = -dL_dk, nl = -dL_dl are formed directly (operand order), the sign of the third row rides on source modifiers.
-	const float nkx = o.lz * dpy - o.ly * dpz, nky = o.lx * dpz - o.lz * dpx, nkz = o.ly * dpx - o.lx * dpy;
-	const float nlx = dpz * o.ky - dpy * o.kz, nly = dpx * o.kz - dpz * o.kx, nlz = dpy * o.kx - dpx * o.ky;
-	v[SA_T + 0] = nkx; v[SA_T + 1] = nky; v[SA_T + 2] = nkz;
-	v[SA_T + 3] = nlx; v[SA_T + 4] = nly; v[SA_T + 5] = nlz;
-	v[SA_T + 6] = dL_dz * sx - (pixx * nkx + pixy * nlx);
-	v[SA_T + 7] = dL_dz * sy - (pixx * nky + pixy * nly);
-	v[SA_T + 8] = dL_dz - (pixx * nkz + pixy * nlz);
+	// dL_ds = nG * s + dL_dz * Tw.xy on the ray-splat branch, 0 on the low-pass branch
+	v2f dL_ds = __builtin_elementwise_fma(mk2(nG, nG), sxy, mk2(dL_dz, dL_dz) * R.Twxy());
+	dL_ds = mk2(use3d ? dL_ds.x : 0.f, use3d ? dL_ds.y : 0.f);
+	const v2f dp = dL_ds * o.inv_pz;                       // dL_dp.xy
+	const v2f dps = dp * sxy;
+	const float dpz = -(dps.x + dps.y);
+	// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k).  With X = (k.x, l.x) etc. the pairs
+	//   N1 = X~ ... : (nk.x, -nl.x) = Z.yx * dp.y - Y.yx * dp.z,  (nk.y, -nl.y) = X.yx * dp.z - Z.yx * dp.x,
+	//   (nk.z, -nl.z) = Y.yx * dp.x - X.yx * dp.y      with nk = -dL_dk, nl = -dL_dl (what the T rows receive)
+	// cost two packed instructions each.  The accumulator therefore holds -nl in slots SA_T+3..5; the per-Gaussian
+	// backward flips the sign when it reads them.
+	const v2f Xs = o.X.yx, Ys = o.Y.yx, Zs = o.Z.yx;
+	const v2f dpx2 = mk2(dp.x, dp.x), dpy2 = mk2(dp.y, dp.y), dpz2 = mk2(dpz, dpz);
+	const v2f N1 = __builtin_elementwise_fma(Zs, dpy2, -(Ys * dpz2));
+	const v2f N2 = __builtin_elementwise_fma(Xs, dpz2, -(Zs * dpx2));
+	const v2f N3 = __builtin_elementwise_fma(Ys, dpx2, -(Xs * dpy2));
+	v[SA_T + 0] = N1.x; v[SA_T + 1] = N2.x; v[SA_T + 2] = N3.x;
+	v[SA_T + 3] = N1.y; v[SA_T + 4] = N2.y; v[SA_T + 5] = N3.y;       // = -nl
+	// third row: dL_dz * (s, 1) - (pix.x * nk + pix.y * nl) = dL_dz * (s, 1) - (pixm . N), pixm = (pix.x, -pix.y)
+	const v2f t1 = N1 * s.pixm, t2 = N2 * s.pixm, t3 = N3 * s.pixm;
+	v[SA_T + 6] = dL_dz * sxy.x - (t1.x + t1.y);
+	v[SA_T + 7] = dL_dz * sxy.y - (t2.x + t2.y);
+	v[SA_T + 8] = dL_dz - (t3.x + t3.y);
 	const float g2 = use3d ? 0.f : nG * S_FILTER_INV_SQ;   // low-pass branch: gradient to the 2D centre only
-	v[SA_MEAN2D + 0] = g2 * o.dx;
-	v[SA_MEAN2D + 1] = g2 * o.dy;
+	const v2f gm = o.d * g2;
+	v[SA_MEAN2D + 0] = gm.x;
+	v[SA_MEAN2D + 1] = gm.y;
 	v[SA_OPAC] = G * dL_dalpha;
 }
 
@@ -535,7 +588,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
                               int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                               const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
                               float* __restrict__ acc) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, contiguous per XCD
+	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, chunked round-robin over the XCDs
 	if (unit >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = unit >> 2, quad = unit & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -555,8 +608,10 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
 	__shared__ uint32_t s_hj[S_WBATCH];    // its position inside the batch
 
+	const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;   // upper half of the row / of the 8-lane half (row_reduce4)
 	SurfelBwdPix st;
 	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
+	st.pixm = mk2(pixx, -pixy);
 	// entries at or beyond the furthest last-contributor of the 64 pixels can be dropped for the whole wave
 	int wave_last = st.last_contributor;
 #pragma unroll
@@ -586,6 +641,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			s_hj[k] = (uint32_t)lane;
 		}
 		__syncthreads();
+		if (dev_flags & 16) { __syncthreads(); continue; }   // development ablation: vote + compaction only
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
 		// ---- 3. blend the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
@@ -593,12 +649,17 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
 		// current one is being differentiated.
 		unsigned long long touched = 0ull;
+		{   // the slab rows of this batch start at zero: the four 16-lane rows add their totals into them
+			float4* zs = s_slab;
+			for (int i = lane; i < nh * (S_ACC_F / 4); i += 64) zs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+			__syncthreads();
+		}
 		// Ping-pong between two SGPR record buffers (A, B): the s_load of the next record is issued right after the
 		// ray-splat evaluation of the current one and is only waited for one full gradient section later.  (With a
 		// single rotating buffer the compiler copies the loaded SGPRs and waits for the load immediately.)
-		struct Rec { float4 r0, r1, r2, r3, r4; };
+		using Rec = SurfelRec;
 		auto fetch = [&](int k) -> Rec {
-			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, (dev_flags & 32) ? 0 : k) * S_REC_F4;   // (32: ablation, one record)
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
 		};
 		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
@@ -606,7 +667,15 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			SurfelPair o;
 			// evaluated for all 64 lanes (no short-circuit): the straight-line gradient code below multiplies every field of
 			// `o` by zero in rejected lanes, so the fields must be defined (finite) there too
-			const bool pair_ok = surfel_pair<false>(R.r0, R.r1, R.r2, R.r3.z, pixx, pixy, o);
+			bool pair_ok;
+			if (dev_flags & 128) {        // development ablation: no ray-splat evaluation (loop + fetch overhead only)
+				o.X = o.Y = o.Z = o.s = o.d = R.xy();
+				o.pz = o.inv_pz = o.rho3d = o.rho2d = o.depth = o.G = 1.0f;
+				o.alpha = R.opac() * 0.5f;
+				pair_ok = R.r0.x + pixx > -1e30f;
+			} else {
+				pair_ok = surfel_pair<false>(R, pixx, pixy, o);
+			}
 			const bool ok = inside && contributor < st.last_contributor && pair_ok;
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
@@ -614,16 +683,26 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			if (__ballot(ok) == 0ull) return;
 			float v[S_ACC_F];
 			v[S_ACC_F - 1] = 0.f;
-			surfel_bwd_pair(st, o, ok, R.r2, R.r3, R.r4, contributor, pixx, pixy, v);
+			if (dev_flags & 8) {          // development ablation: no gradient math (keeps the pair evaluation alive)
+#pragma unroll
+				for (int q = 0; q < S_ACC_F; q++) v[q] = ok ? o.alpha + (float)q : 0.f;
+			} else {
+				surfel_bwd_pair(st, o, ok, R, contributor, v);
+			}
 			// 20 values -> 5 registers of 4 folded values -> row sums; lanes 15/31/47/63 park one value each
+			// 20 values -> 5 registers: in-row packed reduction, then the four row totals meet in LDS (ds_add_f32)
 			float z[5];
+			if (dev_flags & 64) {         // development ablation: no cross-lane work at all
 #pragma unroll
-			for (int g = 0; g < 5; g++) z[g] = fold4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-			row_sum5(z);
-			if ((lane & 15) == 15) {
-				float* slab = reinterpret_cast<float*>(s_slab) + k * S_ACC_F + fold_slot(lane);
+				for (int g = 0; g < 5; g++) z[g] = (v[4 * g] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
+			} else {
+				row_reduce_groups<5>(v, z, up8, up4);
+				quad_sum5(z);
+			}
+			if ((lane & 3) == 0 && !(dev_flags & 2)) {
+				float* slab = reinterpret_cast<float*>(s_slab) + k * S_ACC_F + row_reduce_slot(lane);
 #pragma unroll
-				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
+				for (int g = 0; g < 5; g++) atomicAdd(slab + 4 * g, z[g]);
 			}
 			touched |= 1ull << k;
 		};
@@ -679,7 +758,8 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3], a4v = a4[4];
 	const float gcol[3] = {a0.x, a0.y, a0.z};
 	const float gnrm[3] = {a1.x, a1.y, a1.z};
-	float dT[9] = {a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4v.x};  // render-accumulated dL_dtransMat
+	// render-accumulated dL_dtransMat; the tile kernel accumulates the Tv row with the opposite sign (see surfel_bwd_pair)
+	float dT[9] = {a2.x, a2.y, a2.z, -a2.w, -a3.x, -a3.y, a3.z, a3.w, a4v.x};
 	const float gm2x = a4v.y, gm2y = a4v.z;
 	dL_dcolor[3 * idx] = gcol[0]; dL_dcolor[3 * idx + 1] = gcol[1]; dL_dcolor[3 * idx + 2] = gcol[2];
 	dL_drefl[idx] = a0.w;
@@ -705,7 +785,7 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 		const float4* rc = rec + (size_t)idx * S_REC_F4;
 		if (precomp) {
 			const float4 r0 = rc[0], r1 = rc[1], r2 = rc[2];
-			T = m3_make(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z);
+			T = m3_make(r0.z, r1.x, r1.z, r0.w, r1.y, r1.w, r2.x, r2.y, r2.z);   // (Tu | Tv | Tw) from the paired record layout
 		} else {
 			R = quat_to_rotmat(rotations + 4 * idx, qw, qx, qy, qz);
 			sc0 = scales[2 * idx]; sc1 = scales[2 * idx + 1];   // scale_to_mat(scale, 1.0f): scale_modifier ignored (backward.cu:511)
@@ -866,9 +946,8 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
 	if (R < 0) return R;
 
-	const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
-	const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 	                                                         option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
 	                                                         out_refl_strength_map, gaussian_weights); }
@@ -903,9 +982,8 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
 	if (R > 0) {
-		const int nblocks = ((ntiles + 7) / 8) * 8;
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
-		const int nunits = ((ntiles * 4 + 7) / 8) * 8;
+		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		auto kern = surfel_render_bwd_wave_kernel;
 		kern<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
 		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
