@@ -329,7 +329,7 @@ __device__ __forceinline__ bool cull_hit(const float4 c0, const float4 c1, float
 // Chunks of XCD_CHUNK consecutive units are therefore dealt round-robin: locality inside a chunk, balance across the image.
 // Pure performance; any bijective mapping is correct.  The caller launches a multiple of 8 * XCD_CHUNK workgroups and
 // drops units >= nunits.
-#define XCD_CHUNK 64
+#define XCD_CHUNK 32
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t nunits) {
 	(void)nunits;
 	const uint32_t xcd = bid & 7u, j = bid >> 3;

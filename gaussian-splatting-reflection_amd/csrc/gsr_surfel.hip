@@ -306,6 +306,7 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // touched surfel.  The wave stops as soon as ITS 64 pixels are saturated: no workgroup barriers, no waiting
 // for the other three quadrants (the reference synchronises the 256 threads of a tile twice per batch).
 #define S_WBATCH 64
+#define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 __global__ void __launch_bounds__(64)
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
@@ -604,7 +605,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	const size_t pix = (size_t)W * py + px;
 	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float4 s_slab[S_WBATCH * (S_ACC_F / 4)];
+	__shared__ float4 s_slab[S_SUB * 4 * (S_ACC_F / 4)];   // [hit in sub-batch][16-lane row][20 floats]
 	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
 	__shared__ uint32_t s_hj[S_WBATCH];    // its position inside the batch
 
@@ -641,7 +642,6 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			s_hj[k] = (uint32_t)lane;
 		}
 		__syncthreads();
-		if (dev_flags & 16) { __syncthreads(); continue; }   // development ablation: vote + compaction only
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
 		// ---- 3. blend the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
@@ -649,17 +649,12 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
 		// current one is being differentiated.
 		unsigned long long touched = 0ull;
-		{   // the slab rows of this batch start at zero: the four 16-lane rows add their totals into them
-			float4* zs = s_slab;
-			for (int i = lane; i < nh * (S_ACC_F / 4); i += 64) zs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-			__syncthreads();
-		}
 		// Ping-pong between two SGPR record buffers (A, B): the s_load of the next record is issued right after the
 		// ray-splat evaluation of the current one and is only waited for one full gradient section later.  (With a
 		// single rotating buffer the compiler copies the loaded SGPRs and waits for the load immediately.)
 		using Rec = SurfelRec;
 		auto fetch = [&](int k) -> Rec {
-			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, (dev_flags & 32) ? 0 : k) * S_REC_F4;   // (32: ablation, one record)
+			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
 		};
 		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
@@ -667,15 +662,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			SurfelPair o;
 			// evaluated for all 64 lanes (no short-circuit): the straight-line gradient code below multiplies every field of
 			// `o` by zero in rejected lanes, so the fields must be defined (finite) there too
-			bool pair_ok;
-			if (dev_flags & 128) {        // development ablation: no ray-splat evaluation (loop + fetch overhead only)
-				o.X = o.Y = o.Z = o.s = o.d = R.xy();
-				o.pz = o.inv_pz = o.rho3d = o.rho2d = o.depth = o.G = 1.0f;
-				o.alpha = R.opac() * 0.5f;
-				pair_ok = R.r0.x + pixx > -1e30f;
-			} else {
-				pair_ok = surfel_pair<false>(R, pixx, pixy, o);
-			}
+			const bool pair_ok = surfel_pair<false>(R, pixx, pixy, o);
 			const bool ok = inside && contributor < st.last_contributor && pair_ok;
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
@@ -683,45 +670,44 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 			if (__ballot(ok) == 0ull) return;
 			float v[S_ACC_F];
 			v[S_ACC_F - 1] = 0.f;
-			if (dev_flags & 8) {          // development ablation: no gradient math (keeps the pair evaluation alive)
-#pragma unroll
-				for (int q = 0; q < S_ACC_F; q++) v[q] = ok ? o.alpha + (float)q : 0.f;
-			} else {
-				surfel_bwd_pair(st, o, ok, R, contributor, v);
-			}
-			// 20 values -> 5 registers of 4 folded values -> row sums; lanes 15/31/47/63 park one value each
-			// 20 values -> 5 registers: in-row packed reduction, then the four row totals meet in LDS (ds_add_f32)
+			surfel_bwd_pair(st, o, ok, R, contributor, v);
+			// 20 values -> 5 registers of row totals (exchange-type DPP only); quad q of row r parks value slot(q) of each
+			// register in the slab row of (hit, r).  The four rows are added up by the flush.
 			float z[5];
-			if (dev_flags & 64) {         // development ablation: no cross-lane work at all
+			row_reduce_groups<5>(v, z, up8, up4);
+			quad_sum5(z);
+			if ((lane & 3) == 0) {
+				float* slab = reinterpret_cast<float*>(s_slab) + (((k & (S_SUB - 1)) * 4 + (lane >> 4)) * S_ACC_F) + row_reduce_slot(lane);
 #pragma unroll
-				for (int g = 0; g < 5; g++) z[g] = (v[4 * g] + v[4 * g + 1]) + (v[4 * g + 2] + v[4 * g + 3]);
-			} else {
-				row_reduce_groups<5>(v, z, up8, up4);
-				quad_sum5(z);
-			}
-			if ((lane & 3) == 0 && !(dev_flags & 2)) {
-				float* slab = reinterpret_cast<float*>(s_slab) + k * S_ACC_F + row_reduce_slot(lane);
-#pragma unroll
-				for (int g = 0; g < 5; g++) atomicAdd(slab + 4 * g, z[g]);
+				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
 			}
 			touched |= 1ull << k;
+		};
+		// ---- 4. flush, every S_SUB hits: lane -> (hit, float d); the four row totals are added here and leave as 80
+		// contiguous bytes of float atomics per surfel
+		auto flush = [&](int k_last) {
+			const int k0 = k_last & ~(S_SUB - 1);
+			__syncthreads();
+			if (touched != 0ull && !(dev_flags & 1)) {
+				const float* slab = reinterpret_cast<const float*>(s_slab);
+				const int n = (k_last - k0 + 1) * S_ACC_F;
+				for (int item = lane; item < n; item += 64) {
+					const int kk = item / S_ACC_F, d = item - kk * S_ACC_F;
+					if (d < S_ACC_F - 1 && ((touched >> (k0 + kk)) & 1ull)) {
+						const float* row = slab + kk * 4 * S_ACC_F + d;
+						atomicAdd(acc + (size_t)s_hid[k0 + kk] * S_ACC_F + d, (row[0] + row[S_ACC_F]) + (row[2 * S_ACC_F] + row[3 * S_ACC_F]));
+					}
+				}
+			}
+			__syncthreads();
 		};
 		Rec A = fetch(0), B = A;
 		for (int k = 0; k < nh; k += 2) {
 			differentiate(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); });
-			if (k + 1 >= nh) break;
+			if (k + 1 >= nh) { flush(k); break; }
 			differentiate(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); });
+			if (((k + 1) & (S_SUB - 1)) == S_SUB - 1 || k + 2 >= nh) flush(k + 1);
 		}
-		__syncthreads();
-		// ---- 4. flush: lane -> (hit k, float d); 80 contiguous bytes per surfel
-		if (touched != 0ull && !(dev_flags & 1)) {
-			const float* slab = reinterpret_cast<const float*>(s_slab);
-			for (int item = lane; item < nh * S_ACC_F; item += 64) {
-				const int k = item / S_ACC_F, d = item - k * S_ACC_F;
-				if (d < S_ACC_F - 1 && ((touched >> k) & 1ull)) atomicAdd(acc + (size_t)s_hid[k] * S_ACC_F + d, slab[item]);
-			}
-		}
-		__syncthreads();
 	}
 }
 
