@@ -194,6 +194,7 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 // gsr_surfel.hip for the design: one wave = one 8x8 pixel block, ballot-compacted private work list from
 // conservative cull bounds, per-Gaussian record through the scalar memory path, no workgroup barriers).
 #define G_WBATCH 64
+#define G_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
 gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
@@ -325,10 +326,11 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	const size_t pix = (size_t)W * py + px;
 	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
-	__shared__ float s_slab[G_WBATCH * G_ACC_F];
+	__shared__ float s_slab[G_SUB * 4 * G_ACC_F];   // [hit in sub-batch][16-lane row][16 floats]
 	__shared__ uint32_t s_hid[G_WBATCH];
 	__shared__ uint32_t s_hj[G_WBATCH];
 
+	const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;   // row_reduce_groups lane predicates
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
 	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
@@ -428,31 +430,40 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			v[GA_CONIC + 1] = hg * gdx * dy;
 			v[GA_CONIC + 2] = hg * gdy * dy;
 			v[GA_OPAC] = G * dL_dalpha;
+			// 16 values -> 4 registers of row totals (exchange-type DPP, see row_reduce_groups); the four 16-lane rows park
+			// theirs in separate slab rows and the flush adds them (as in surfel_render_bwd_wave_kernel)
 			float z[4];
-#pragma unroll
-			for (int g = 0; g < 4; g++) z[g] = fold4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-			row_sum4(z);
-			if ((lane & 15) == 15) {
-				float* slab = s_slab + k * G_ACC_F + fold_slot(lane);
+			row_reduce_groups<4>(v, z, up8, up4);
+			quad_sum4(z);
+			if ((lane & 3) == 0) {
+				float* slab = s_slab + (((k & (G_SUB - 1)) * 4 + (lane >> 4)) * G_ACC_F) + row_reduce_slot(lane);
 #pragma unroll
 				for (int g = 0; g < 4; g++) slab[4 * g] = z[g];
 			}
 			touched |= 1ull << k;
 		};
+		auto flush = [&](int k_last) {
+			const int k0 = k_last & ~(G_SUB - 1);
+			__syncthreads();
+			if (touched != 0ull) {
+				const int n = (k_last - k0 + 1) * G_ACC_F;
+				for (int item = lane; item < n; item += 64) {
+					const int kk = item / G_ACC_F, d = item - kk * G_ACC_F;
+					if ((touched >> (k0 + kk)) & 1ull) {
+						const float* row = s_slab + kk * 4 * G_ACC_F + d;
+						atomicAdd(acc + (size_t)s_hid[k0 + kk] * G_ACC_F + d, (row[0] + row[G_ACC_F]) + (row[2 * G_ACC_F] + row[3 * G_ACC_F]));
+					}
+				}
+			}
+			__syncthreads();
+		};
 		Rec A = fetch(0), B = A;
 		for (int k = 0; k < nh; k += 2) {
 			differentiate(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); });
-			if (k + 1 >= nh) break;
+			if (k + 1 >= nh) { flush(k); break; }
 			differentiate(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); });
+			if (((k + 1) & (G_SUB - 1)) == G_SUB - 1 || k + 2 >= nh) flush(k + 1);
 		}
-		__syncthreads();
-		if (touched != 0ull) {
-			for (int item = lane; item < nh * G_ACC_F; item += 64) {
-				const int k = item / G_ACC_F, d = item - k * G_ACC_F;
-				if ((touched >> k) & 1ull) atomicAdd(acc + (size_t)s_hid[k] * G_ACC_F + d, s_slab[item]);
-			}
-		}
-		__syncthreads();
 	}
 }
 
