@@ -711,8 +711,8 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	}
 }
 
-// 71 VGPRs.  Measured at C3 with amdgpu_waves_per_eu = 4 / 5 / 6 / unconstrained (7): 2.11 / 2.07 / 2.04 / 2.13 ms.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
+// 75 VGPRs.  Measured at C3 (balanced XCD mapping) with amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
                               const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
