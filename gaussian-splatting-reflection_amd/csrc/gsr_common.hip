@@ -129,6 +129,7 @@ ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int pla
 	s.ranges = c.take<uint2>(tiles);
 	s.final_T = c.take<float>(HW * planes_T);
 	s.n_contrib = c.take<uint32_t>(HW * planes_n);
+	s.tile_order = c.take<uint32_t>(tiles);
 	if (total) *total = c.size();
 	return s;
 }
@@ -186,6 +187,42 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t*
 		}
 	}
 	if (idx == L - 1) ranges[currtile].y = L;
+}
+
+// Longest-first dispatch order of the tiles in ONE single-workgroup kernel: a counting sort on the list length quantised
+// to 1024 buckets (list scheduling only needs an approximate order; a full rocPRIM sort of ~8 k keys costs 30 us in
+// launches).  Order inside a bucket is whatever the LDS atomics produce; any permutation is correct.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+	__shared__ uint32_t hist[1024];
+	__shared__ uint32_t s_max;
+	const int t = threadIdx.x;
+	hist[t] = 0;
+	if (t == 0) s_max = 0;
+	__syncthreads();
+	uint32_t m = 0;
+	for (int i = t; i < tiles; i += 1024) m = max(m, ranges[i].y - ranges[i].x);
+	atomicMax(&s_max, m);
+	__syncthreads();
+	int shift = 0;
+	while ((s_max >> shift) >= 1024u) shift++;
+	for (int i = t; i < tiles; i += 1024) atomicAdd(&hist[1023u - ((ranges[i].y - ranges[i].x) >> shift)], 1u);   // bucket 0 = longest
+	__syncthreads();
+	// exclusive scan of the 1024 buckets (Hillis-Steele in LDS)
+	const uint32_t mine = hist[t];
+	uint32_t v = mine;
+	for (int off = 1; off < 1024; off <<= 1) {
+		const uint32_t o = t >= off ? hist[t - off] : 0u;
+		__syncthreads();
+		v += o;
+		hist[t] = v;
+		__syncthreads();
+	}
+	hist[t] = v - mine;
+	__syncthreads();
+	for (int i = t; i < tiles; i += 1024) {
+		const uint32_t b = 1023u - ((ranges[i].y - ranges[i].x) >> shift);
+		order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
+	}
 }
 
 // debug only: the reference's sorted 64-bit keys, rebuilt from the sorted tile ids and the depth of each instance
@@ -266,7 +303,17 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.tile_keys, img.ranges); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
+	{ StageTimer st_(GSR_STAGE_RANGES, stream);
+	const int rc = run_tile_order(img, tiles, stream);
+	if (rc < 0) return rc; }
 	return R;
+}
+
+int run_tile_order(const ImageState& img, size_t tiles, hipStream_t stream) {
+	if (tiles == 0) return 0;
+	tile_order_kernel<<<1, 1024, 0, stream>>>((int)tiles, img.ranges, img.tile_order);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ pts, const float* __restrict__ vm,

@@ -197,13 +197,13 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 #define G_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
-gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                              const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                              float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);
-	if (unit >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = unit >> 2, quad = unit & 3u;
+	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
+	if (slot >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -305,14 +305,14 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 // and flushes one 64-byte row of atomics per touched Gaussian into acc[P][16].
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
-gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
                              const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                              const float* __restrict__ dL_dnormal_map, const float* __restrict__ dL_drefl_map,
                              const float* __restrict__ dL_invdepths, float* __restrict__ acc) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);
-	if (unit >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = unit >> 2, quad = unit & 3u;
+	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
+	if (slot >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -703,11 +703,11 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	{
 		StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
 		if (out_invdepth)
-			gauss_render_fwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+			gauss_render_fwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 			                                                              option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
 			                                                              out_refl_strength_map, out_invdepth);
 		else
-			gauss_render_fwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+			gauss_render_fwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 			                                                               option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
 			                                                               out_refl_strength_map, nullptr);
 	}
@@ -747,11 +747,11 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 		{
 			StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 			if (dL_invdepths)
-				gauss_render_bwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+				gauss_render_bwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 				                                                              geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
 				                                                              dL_drefl_strength_map, dL_invdepths, geom.acc);
 			else
-				gauss_render_bwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+				gauss_render_bwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 				                                                               geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
 				                                                               dL_drefl_strength_map, nullptr, geom.acc);
 		}

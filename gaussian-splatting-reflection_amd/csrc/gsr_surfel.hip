@@ -308,13 +308,13 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 #define S_WBATCH 64
 #define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 __global__ void __launch_bounds__(64)
-surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                               float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, chunked round-robin over the XCDs
-	if (unit >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = unit >> 2, quad = unit & 3u;
+	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
+	if (slot >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -584,14 +584,14 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 // No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
 // threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
 __device__ __forceinline__ void
-surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
                               int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                               const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
                               float* __restrict__ acc) {
-	const uint32_t unit = xcd_tile(blockIdx.x, ntiles * 4);   // (tile, quadrant) units, chunked round-robin over the XCDs
-	if (unit >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = unit >> 2, quad = unit & 3u;
+	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
+	if (slot >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -713,11 +713,11 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 
 // 75 VGPRs.  Measured at C3 (balanced XCD mapping) with amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
                               const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                               const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
-	surfel_render_bwd_wave_body(ranges, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
+	surfel_render_bwd_wave_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
 	                            dL_depths, dL_drefl_map, acc);
 }
 
@@ -934,7 +934,7 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 
 { StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
 	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
-	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 	                                                         option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
 	                                                         out_refl_strength_map, gaussian_weights); }
 	GSR_LAUNCH_CHECK(debug, stream);
@@ -971,7 +971,7 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		auto kern = surfel_render_bwd_wave_kernel;
-		kern<<<nunits, 64, 0, stream>>>(img.ranges, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
+		kern<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
 		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
