@@ -28,10 +28,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fhip-fp32-corr
 # Per-file flags.  The tile kernels keep their per-Gaussian record in SGPRs; clang's SLP vectoriser turns pairs of
 # scalar FMAs into v_pk_* instructions whose SGPR operands must be even-aligned pairs, so it re-packs the freshly loaded
 # record with ~25 s_mov per (wave, Gaussian) pair and waits for the scalar load immediately instead of one pair later.
-# Scalar issue slots are as scarce as vector ones here (measured: tests/ablate notes in DESIGN.md), so SLP is off for them.
-# Variant G's record is 16 dwords and its conic math packs without re-shuffling: there SLP helps (fwd 0.44 vs 0.56 ms at
-# 1 M Gaussians), so only the surfel kernels opt out (fwd 1.24 -> 1.15 ms, bwd 2.43 -> 2.10 ms at C3).
-EXTRA_FLAGS = {"gsr_surfel.hip": ["-fno-slp-vectorize"]}
+# Scalar issue slots are as scarce as vector ones here, so SLP is off for both variants; the packed math that pays
+# is written explicitly on <2 x float> against a record laid out in aligned pairs (gsr_surfel.hip).  Measured at 1 M
+# Gaussians, variant G: fwd 0.27 / 0.30 ms, bwd 0.70 / 0.63 ms with / without SLP; variant S: see DESIGN.md.
+EXTRA_FLAGS = {"gsr_surfel.hip": ["-fno-slp-vectorize"], "gsr_gauss.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("GSR_SLP") == "1":      # development switch for A/B measurements
     EXTRA_FLAGS = {}
 
