@@ -100,7 +100,7 @@ def main():
     from gaussian_renderer import deferred_reflection
 
     if os.environ.get("GSR_DEV"):
-        _gsr.set_option("dev", int(os.environ["GSR_DEV"]))   # development ablations only (tests/ablate.py)
+        _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))   # development ablations only (tests/ablate.py)
     P, W, H = args.gaussians, args.width, args.height
     scene = Scene(S, P, args.mu, args.cubemap, dev, seed=1003)
     cam = yaw_camera(S, W, H, 3.0 * rank)

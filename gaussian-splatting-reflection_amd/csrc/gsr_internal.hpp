@@ -99,7 +99,7 @@ ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int pla
 BinningState carve_binning(void* buf, size_t R, size_t sort_temp_bytes, size_t* total);
 
 int option_cull();   // 1 (default): per-wave bounding-box culling in the tile kernels; 0: evaluate every list entry
-int option_dev();    // development ablation bits (0 in production): 1 = skip gradient atomics, 2 = skip wave reductions
+int option_dev();    // development ablation bits (0 in production): 1 = skip the gradient atomics of the surfel backward
 size_t scan_temp_bytes(size_t P);
 size_t sort_temp_bytes(size_t R, int end_bit);
 int run_tile_order(const ImageState& img, size_t tiles, hipStream_t stream);
