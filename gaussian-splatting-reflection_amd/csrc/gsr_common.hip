@@ -426,6 +426,7 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	if (n == "depths") return d2d(g.depths, (size_t)P * 4);
 	if (n == "means2D") return d2d(g.means2D, (size_t)P * 8);
 	if (n == "tiles_touched") return d2d(g.tiles_touched, (size_t)P * 4);
+	if (n == "cull") return d2d(g.bbox, (size_t)P * 32);   // two float4 per Gaussian (see cull_hit)
 	if (n == "point_offsets") return d2d(g.point_offsets, (size_t)P * 4);
 	if (n == "clamped") {
 		if (P == 0) return 0;

@@ -129,12 +129,17 @@ __device__ __forceinline__ void surfel_cull_record(const M3& T, float cx, float 
 	const double C22 = j02 * j02 + j12 * j12 - c2 * j22 * j22;
 	const double det2 = C00 * C11 - C01 * C01;
 	if (!(det2 > 0.0) || !(C00 > 0.0)) return;
+	// A surfel seen nearly edge-on projects to a sliver.  There the fp32 ray-splat evaluation of the tile kernels (and of
+	// the reference) is numerical noise — a pixel 16 px away from a 0.03 px wide sliver was seen to evaluate to
+	// alpha = 0.007 at C3 — and that noise is part of the result to reproduce, so slivers are never culled: conic
+	// close to singular, or (below) minor semi-axis under half a pixel.
+	if (!(det2 > 1e-6 * C00 * C11)) return;
 	const double ex = -(C11 * C02 - C01 * C12) / det2, ey = -(C00 * C12 - C01 * C02) / det2;
 	const double q0 = C22 + C02 * ex + C12 * ey;
 	if (!(q0 < 0.0)) return;
 	const double sc = 1.0 / (-q0 * 1.02);
 	const float fa = (float)(C00 * sc), fb = (float)(C01 * sc), fc = (float)(C11 * sc);
-	if (!(fa > 0.f) || !(fc > 0.f) || !(fa * fc - fb * fb > 0.f) || !(fabsf((float)ex) < 1e7f) || !(fabsf((float)ey) < 1e7f)) return;
+	if (!(fa > 0.f) || !(fc > 0.f) || !(fa * fc - fb * fb > 0.f) || !(fa + fc < 4.0f) || !(fabsf((float)ex) < 1e7f) || !(fabsf((float)ey) < 1e7f)) return;
 	c0 = make_float4((float)ex, (float)ey, fa, fb);
 	c1.x = fc;
 }
@@ -433,7 +438,9 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		final_T[HW + pix] = DM.y;
 		final_T[2 * HW + pix] = M2;
 		n_contrib[pix] = last_contributor;
-		n_contrib[HW + pix] = (uint32_t)median_contributor;  // v_cvt_u32_f32 saturates: -1 -> 0, as cvt.rzi.u32.f32 does
+		// the reference converts the float -1 of "no median" with cvt.rzi.u32.f32, which saturates to 0; in C++ that
+		// conversion is undefined (and clang does exploit it), so the clamp is explicit
+		n_contrib[HW + pix] = (uint32_t)fmaxf(median_contributor, 0.0f);
 		out_color[pix] = Crg.x + T * bg[0];
 		out_color[HW + pix] = Crg.y + T * bg[1];
 		out_color[2 * HW + pix] = C2 + T * bg[2];

@@ -208,3 +208,17 @@ def test_grad_sink_routes_gradients_into_caller_buffers():
         assert np.isfinite(got).all(), k
         ref = plain[names[k]].reshape(got.shape)
         assert rel_maxnorm(got, ref) <= 5e-5, k                    # atomics order differs run to run
+
+
+def test_pixels_without_contributors_report_zero_median():
+    """A sparse scene: most pixels see no surfel at all.  Their median-contributor entry is the reference's float -1
+    converted with saturation, i.e. 0 (the C++ conversion is undefined and once compiled to lane garbage)."""
+    orc = _orc()
+    kw, _, _ = scene_kwargs("S", 60, 256, 192, 123, -3.5, 1, (0.2, 0.2, 0.2))
+    o = orc.SurfelOracle(np.float32)
+    ref = o.forward(**kw)
+    hip = HipSurfel(kw)
+    nh, no_ = hip.state("n_contrib").astype(np.int64), o.state("n_contrib").astype(np.int64)
+    assert (no_[0] == 0).mean() > 0.5
+    np.testing.assert_array_equal(nh, no_)
+    np.testing.assert_array_equal(hip.out()["color"][:, no_[0] == 0], ref["color"][:, no_[0] == 0])
