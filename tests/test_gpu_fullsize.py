@@ -87,3 +87,25 @@ def test_c3_against_oracle(c3):
     gh = hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
     for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_drefl_strengths"):
         assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
+
+
+def test_full_size_gauss_variant_against_oracle():
+    """Variant G at the same size (10^6 Gaussians, 1080p, SH 3, anti-aliasing + inverse depth)."""
+    from helpers import HipGauss
+    from oracle import oracle as orc
+    kw, cam, sc = scene_kwargs("G", P, W, H, 1003, -4.75, 3, (0, 0, 0))
+    o = orc.GaussOracle(np.float32)
+    ref = o.forward(antialiasing=True, **kw)
+    hip = HipGauss(kw, antialiasing=True)
+    out = hip.out()
+    assert out["num_rendered"] == ref["num_rendered"]
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
+    assert (hip.state("n_contrib").astype(np.int64) != o.state("n_contrib").astype(np.int64)).mean() <= 1e-4
+    for k in ("color", "normal_map", "invdepth", "refl_strength_map"):
+        assert psnr(out[k], ref[k], peak=max(1.0, float(np.abs(ref[k]).max()))) >= 50, k
+    g = S.make_upstream_grads(H, W, 1003)
+    gr = o.backward(dL_dcolor=g["dL_dcolor"], dL_dinvdepth=g["dL_dinvdepth"], dL_dnormal_map=g["dL_dnormal"], dL_drefl_strength_map=g["dL_drefl"])
+    gh = hip.backward(g["dL_dcolor"], g["dL_dinvdepth"], g["dL_dnormal"], g["dL_drefl"])
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dnormals", "dL_drefl_strengths"):
+        assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
