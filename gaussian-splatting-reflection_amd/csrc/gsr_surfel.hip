@@ -96,50 +96,43 @@ __device__ __forceinline__ void compute_transmat(float px, float py, float pz, c
 // Cull record of a surfel (see cull_hit() in gsr_internal.hpp): a superset of the pixels it can blend into.
 // alpha = min(0.99, opa * exp(-rho/2)) >= 1/255 needs rho <= rho_max = 2 ln(255 opa), rho = min(rho3d, rho2d):
 //   * rho3d <= c2 is the image of the splat-space disc u^2+v^2 <= c2 under the homography pix_h = A (u,v,1)^T,
-//     A = rows (Tu, Tv, Tw): the conic x^T C x <= 0 with C = A^-T diag(1,1,-c2) A^-1, i.e. (when the disc stays in
-//     front of the camera plane) an ellipse; its centre and shape matrix are extracted here in double precision
-//     (the adjugate products cancel heavily in fp32) and stored normalised to d^T E d <= 1;
+//     A = rows (Tu, Tv, Tw): an ellipse as long as the disc stays in front of the camera plane.  It is extracted from the
+//     DUAL conic Q* = A diag(1,1,-1/c2) A^T = [[S, s],[s^T, sigma]], which needs no inverse of A: centre = s / sigma (the
+//     reference's AABB centre formula), covariance-like shape E^-1 = (S - s s^T / sigma) / (-sigma).  (A first version
+//     inverted A and read centre and scale off the point conic; for surfels seen edge-on — axis ratios beyond 100:1 —
+//     that lost every digit even in double, the footprint came out 10x too short and a contributing pixel was culled:
+//     found by tests/test_gpu_fullsize.py.)
 //   * rho2d <= c2 is the disc of squared radius c2/2 about the low-pass centre (the cutoff-3 AABB centre).
-// c2 carries a 5 % + 0.1 margin over rho_max, the ellipse another 2 %; the per-pixel evaluation of rho3d itself is
-// only good to ~1e-4 relative.  Anything irregular (disc reaching the camera plane, non-ellipse conic, NaN) is
-// encoded as "always a hit"; opa < 1/255 can never blend.  Culling with this record leaves every output
-// bit-identical (tests/test_gpu_parity.py::test_cull_is_bit_exact).
+// c2 carries a 5 % + 0.1 margin over rho_max; the ellipse is grown by 2 % and then dilated by half a pixel
+// (E^-1 += 0.25 I), which also bounds its condition number so that the fp32 vote stays accurate for slivers.
+// Anything irregular (disc reaching the camera plane, non-positive shape, NaN) is encoded as "always a hit";
+// opa < 1/255 can never blend.  Culling with this record leaves every output bit-identical
+// (tests/test_gpu_parity.py::test_cull_is_bit_exact, tests/test_gpu_fullsize.py at C3).
 __device__ __forceinline__ void surfel_cull_record(const M3& T, float cx, float cy, float opa, float4& c0, float4& c1) {
 	c0 = make_float4(cx, cy, 0.f, 0.f);
 	c1 = make_float4(0.f, cx, cy, -2.0f);
 	if (!(opa >= 1.0f / 255.0f)) return;   // never
 	const float c2f = 2.0f * logf(255.0f * opa) * 1.05f + 0.1f;
 	c1.w = 0.5f * c2f * 1.02f;             // disc about the low-pass centre
-	const double c2 = (double)c2f;
+	const double ic2 = 1.0 / (double)c2f;
 	const double a00 = T.m[0][0], a01 = T.m[0][1], a02 = T.m[0][2];   // Tu
 	const double a10 = T.m[1][0], a11 = T.m[1][1], a12 = T.m[1][2];   // Tv
 	const double a20 = T.m[2][0], a21 = T.m[2][1], a22 = T.m[2][2];   // Tw
-	// the cutoff disc must stay strictly in front of the camera plane (w > 0), else the projection is unbounded
-	if (!(c2 * (a20 * a20 + a21 * a21) - a22 * a22 < -1e-6 * a22 * a22)) return;   // a stays 0: always a hit
-	// adjugate of A (inverse up to the factor det, which only rescales the conic)
-	const double j00 = a11 * a22 - a12 * a21, j01 = a02 * a21 - a01 * a22, j02 = a01 * a12 - a02 * a11;
-	const double j10 = a12 * a20 - a10 * a22, j11 = a00 * a22 - a02 * a20, j12 = a02 * a10 - a00 * a12;
-	const double j20 = a10 * a21 - a11 * a20, j21 = a01 * a20 - a00 * a21, j22 = a00 * a11 - a01 * a10;
-	// C = adj^T diag(1,1,-c2) adj
-	const double C00 = j00 * j00 + j10 * j10 - c2 * j20 * j20;
-	const double C01 = j00 * j01 + j10 * j11 - c2 * j20 * j21;
-	const double C11 = j01 * j01 + j11 * j11 - c2 * j21 * j21;
-	const double C02 = j00 * j02 + j10 * j12 - c2 * j20 * j22;
-	const double C12 = j01 * j02 + j11 * j12 - c2 * j21 * j22;
-	const double C22 = j02 * j02 + j12 * j12 - c2 * j22 * j22;
-	const double det2 = C00 * C11 - C01 * C01;
-	if (!(det2 > 0.0) || !(C00 > 0.0)) return;
-	// A surfel seen nearly edge-on projects to a sliver.  There the fp32 ray-splat evaluation of the tile kernels (and of
-	// the reference) is numerical noise — a pixel 16 px away from a 0.03 px wide sliver was seen to evaluate to
-	// alpha = 0.007 at C3 — and that noise is part of the result to reproduce, so slivers are never culled: conic
-	// close to singular, or (below) minor semi-axis under half a pixel.
-	if (!(det2 > 1e-6 * C00 * C11)) return;
-	const double ex = -(C11 * C02 - C01 * C12) / det2, ey = -(C00 * C12 - C01 * C02) / det2;
-	const double q0 = C22 + C02 * ex + C12 * ey;
-	if (!(q0 < 0.0)) return;
-	const double sc = 1.0 / (-q0 * 1.02);
-	const float fa = (float)(C00 * sc), fb = (float)(C01 * sc), fc = (float)(C11 * sc);
-	if (!(fa > 0.f) || !(fc > 0.f) || !(fa * fc - fb * fb > 0.f) || !(fa + fc < 4.0f) || !(fabsf((float)ex) < 1e7f) || !(fabsf((float)ey) < 1e7f)) return;
+	// sigma < 0: the cutoff disc stays strictly in front of the camera plane (w > 0); otherwise the projection is unbounded
+	const double sigma = a20 * a20 + a21 * a21 - a22 * a22 * ic2;
+	if (!(sigma < -1e-6 * a22 * a22 * ic2)) return;   // a stays 0: always a hit
+	const double sx = a00 * a20 + a01 * a21 - a02 * a22 * ic2, sy = a10 * a20 + a11 * a21 - a12 * a22 * ic2;
+	const double Sxx = a00 * a00 + a01 * a01 - a02 * a02 * ic2, Sxy = a00 * a10 + a01 * a11 - a02 * a12 * ic2,
+	             Syy = a10 * a10 + a11 * a11 - a12 * a12 * ic2;
+	const double is = 1.0 / sigma;
+	const double ex = sx * is, ey = sy * is;
+	// E^-1 = (S - s s^T / sigma) / (-sigma), grown by 2 % in length and dilated by half a pixel
+	const double g = -is * 1.0404;
+	const double Vxx = (Sxx - sx * sx * is) * g + 0.25, Vxy = (Sxy - sx * sy * is) * g, Vyy = (Syy - sy * sy * is) * g + 0.25;
+	const double det = Vxx * Vyy - Vxy * Vxy;
+	if (!(Vxx > 0.25) || !(Vyy > 0.25) || !(det > 0.0)) return;
+	const float fa = (float)(Vyy / det), fb = (float)(-Vxy / det), fc = (float)(Vxx / det);
+	if (!(fa > 0.f) || !(fc > 0.f) || !(fa * fc - fb * fb > 0.f) || !(fabsf((float)ex) < 1e7f) || !(fabsf((float)ey) < 1e7f)) return;
 	c0 = make_float4((float)ex, (float)ey, fa, fb);
 	c1.x = fc;
 }
