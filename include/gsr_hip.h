@@ -261,8 +261,9 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 #define GSR_STAGE_SURFACE_FWD 15
 #define GSR_STAGE_SURFACE_BWD 16
 #define GSR_STAGE_COUNT 17
-/* Test/diagnostic switches.  "cull" (default 1): per-wave conservative bounding-box culling inside the tile
- * kernels; outputs are bit-identical with 0 and 1 (it only skips pairs that cannot blend). */
+/* Test/diagnostic switches.  "cull" (default 1): per-wave footprint culling inside the tile kernels (each wave votes
+ * which list entries can reach its 8x8 pixel block at all); outputs are bit-identical with 0 and 1, it only skips
+ * (wave, Gaussian) pairs that cannot blend.  "dev" (default 0): development ablation bits, not for production. */
 int gsr_set_option(const char* name, int value);
 int gsr_profile_enable(int on);
 int gsr_profile_collect(float* ms_out /* [GSR_STAGE_COUNT] */, int* launches_out /* [GSR_STAGE_COUNT] */);
