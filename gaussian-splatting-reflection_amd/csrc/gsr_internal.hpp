@@ -194,30 +194,32 @@ __device__ __forceinline__ void row_sum4(float* z) {
 }
 // ---- in-row packed reduction (exchange-type DPP only; measured on MI355X: v_permlane32/16_swap cost ~4x a DPP add, so
 // the swap-based fold4 above is the SLOWER way to pack on this part — tests/ablate notes in DESIGN.md).
-// Four values (a, b, c, d) per call are reduced over each 16-lane row: level 1 pairs lane i with 15-i (row_mirror) and
+// Four values (a, b, c, d) per group are reduced over each 16-lane row: level 1 pairs lane i with 15-i (row_mirror) and
 // keeps a in lanes 0-7 / b in lanes 8-15, level 2 pairs i with 7-i inside each half (row_half_mirror) and keeps the first
 // pair's result in lanes 0-3 of each half / the second pair's in lanes 4-7; two quad_perm adds finish the row sum.
-// Result: every lane of quad q of a row holds the ROW total of value {a, c, b, d}[q].  3+3+3+2 = 11 instructions per 4
-// values and per row; the four row totals are combined by the caller (LDS atomics).
+// Result: every lane of quad q of a row holds the ROW total of value {a, c, b, d}[q]; the four row totals are combined
+// by the caller (separate LDS rows, added at the flush).
 #define GSR_DPPX(CTRL, dst, dppsrc, src) "v_add_f32_dpp %" #dst ", %" #dppsrc ", %" #src " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
 #define GSR_Q1(CTRL, i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
-// NG groups of four values v[4g..4g+3] -> z[g]; all DPP instructions of one level sit in one asm statement (one s_nop
-// for the VALU-write -> DPP-read hazard per level instead of one per group).
+// NG groups of four values v[4g..4g+3] -> z[g].  No selects: DPP's bank_mask enables the destination per bank of four
+// lanes, so level 1 is two adds into ONE register — `a + mirror(a)` written to lanes 0-7 (banks 0,1), `b + mirror(b)` to
+// lanes 8-15 (banks 2,3) — and level 2 likewise with banks {0,2} / {1,3}.  2+2 (level 1) + 2 (level 2) = 6 instructions
+// per group of four values (up8 / up4 are kept in the signature for callers; they are not needed any more).
+#define GSR_DPPB(CTRL, BANK, dst, src) "v_add_f32_dpp %" #dst ", %" #src ", %" #src " " CTRL " row_mask:0xf bank_mask:" BANK "\n\t"
 template <int NG>
 __device__ __forceinline__ void row_reduce_groups(const float* v, float* z, bool up8, bool up4) {
+	(void)up8; (void)up4;
 	float p[NG], q[NG];
 #pragma unroll
 	for (int g = 0; g < NG; g++) {
-		const float a = v[4 * g], b = v[4 * g + 1], c = v[4 * g + 2], d = v[4 * g + 3];
-		const float k1 = up8 ? b : a, s1 = up8 ? a : b, k2 = up8 ? d : c, s2 = up8 ? c : d;
-		// level 1 (one asm per group keeps the operand count within asm limits; the leading s_nop only matters once)
-		asm volatile("s_nop 1\n\t" GSR_DPPX("row_mirror", 0, 2, 3) GSR_DPPX("row_mirror", 1, 4, 5)
-		             : "=&v"(p[g]), "=&v"(q[g]) : "v"(s1), "v"(k1), "v"(s2), "v"(k2));
+		asm volatile("s_nop 1\n\t" GSR_DPPB("row_mirror", "0x3", 0, 2) GSR_DPPB("row_mirror", "0xc", 0, 3) GSR_DPPB("row_mirror", "0x3", 1, 4)
+		             GSR_DPPB("row_mirror", "0xc", 1, 5)
+		             : "=&v"(p[g]), "=&v"(q[g]) : "v"(v[4 * g]), "v"(v[4 * g + 1]), "v"(v[4 * g + 2]), "v"(v[4 * g + 3]));
 	}
 #pragma unroll
 	for (int g = 0; g < NG; g++) {
-		const float k3 = up4 ? q[g] : p[g], s3 = up4 ? p[g] : q[g];
-		asm volatile("s_nop 1\n\t" GSR_DPPX("row_half_mirror", 0, 1, 2) : "=&v"(z[g]) : "v"(s3), "v"(k3));
+		asm volatile("s_nop 1\n\t" GSR_DPPB("row_half_mirror", "0x5", 0, 1) GSR_DPPB("row_half_mirror", "0xa", 0, 2)
+		             : "=&v"(z[g]) : "v"(p[g]), "v"(q[g]));
 	}
 }
 // levels 3 and 4 (interleaved so that no DPP reads a register written < 2 instructions before)
