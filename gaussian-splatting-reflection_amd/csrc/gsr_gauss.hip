@@ -300,9 +300,9 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 }
 
 // renderCUDA backward (DGR backward.cu:452-690), wave-per-quadrant form.  The reference issues 16 float
-// atomicAdds per contributing (pixel, Gaussian) pair; here the wave folds the 16 values with
-// v_permlane32/16_swap (4 values per register), finishes with four fused DPP row steps, parks the totals in LDS
-// and flushes one 64-byte row of atomics per touched Gaussian into acc[P][16].
+// atomicAdds per contributing (pixel, Gaussian) pair; here the wave reduces the 16 values over each 16-lane row with
+// exchange-type DPP (row_reduce_groups), parks the four row totals in LDS and flushes their sum as one 64-byte row of
+// atomics per touched Gaussian into acc[P][16] (see surfel_render_bwd_wave_body for the full description).
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
 gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,

@@ -156,44 +156,9 @@ __device__ __forceinline__ void wave_sum4(float* v) {
 	             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
-// ---- packed multi-value wave reduction (gfx950 v_permlane32_swap / v_permlane16_swap).
-// Measured on MI355X (tests/microbench/valu_rate.hip): v_add_f32_dpp issues at half the plain VALU rate, so the
-// classic 6-step DPP reduction costs ~12 issue slots per value.  Swapping halves between TWO registers first
-// folds 64 -> 32 lanes for two values with one swap + one add, then 32 -> 16 lanes for four values with one
-// more swap + add; only the last four steps (inside a 16-lane row) need DPP, and they run on a register that
-// carries four values at once.  4 values: 3 swaps + 3 adds + 4 DPP adds (~3.5 slots per value).
-// Result: the totals of (A, C, B, D) sit in lane 15 of rows 0, 1, 2, 3 (lanes 15, 31, 47, 63).
-__device__ __forceinline__ void swap32(float& a, float& b) {
-	auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-	a = __uint_as_float(r[0]);
-	b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap16(float& a, float& b) {
-	auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-	a = __uint_as_float(r[0]);
-	b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float fold4(float A, float B, float C, float D) {
-	swap32(A, B);
-	const float X = A + B;
-	swap32(C, D);
-	const float Y = C + D;
-	float x = X, y = Y;
-	swap16(x, y);
-	return x + y;
-}
-#define GSR_DPP5(CTRL) GSR_DPP1(CTRL, 0) GSR_DPP1(CTRL, 1) GSR_DPP1(CTRL, 2) GSR_DPP1(CTRL, 3) GSR_DPP1(CTRL, 4)
-// inclusive row sums of 5 / 4 registers: totals land in lane 15 of each 16-lane row
-__device__ __forceinline__ void row_sum5(float* z) {
-	asm volatile("s_nop 1\n\t" GSR_DPP5(GSR_SHR1) GSR_DPP5(GSR_SHR2) GSR_DPP5(GSR_SHR4) GSR_DPP5(GSR_SHR8)
-	             : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]));
-}
-__device__ __forceinline__ void row_sum4(float* z) {
-	asm volatile("s_nop 1\n\t" GSR_DPP4(GSR_SHR1) GSR_DPP4(GSR_SHR2) GSR_DPP4(GSR_SHR4) GSR_DPP4(GSR_SHR8)
-	             : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-}
-// ---- in-row packed reduction (exchange-type DPP only; measured on MI355X: v_permlane32/16_swap cost ~4x a DPP add, so
-// the swap-based fold4 above is the SLOWER way to pack on this part — tests/ablate notes in DESIGN.md).
+// ---- in-row packed reduction (exchange-type DPP only).  An earlier version folded 64 -> 16 lanes with
+// v_permlane32_swap / v_permlane16_swap (fewer instructions); measured on MI355X those swaps cost ~4x a DPP add, so
+// that was the SLOWER way to pack on this part (ablation numbers in DESIGN.md).
 // Four values (a, b, c, d) per group are reduced over each 16-lane row: level 1 pairs lane i with 15-i (row_mirror) and
 // keeps a in lanes 0-7 / b in lanes 8-15, level 2 pairs i with 7-i inside each half (row_half_mirror) and keeps the first
 // pair's result in lanes 0-3 of each half / the second pair's in lanes 4-7; two quad_perm adds finish the row sum.
@@ -236,12 +201,6 @@ __device__ __forceinline__ void quad_sum4(float* z) {
 __device__ __forceinline__ int row_reduce_slot(int lane) {
 	const int q = (lane >> 2) & 3;          // quads 0,1,2,3 hold a, c, b, d
 	return ((q & 1) << 1) | (q >> 1);
-}
-
-// slot (0..3) inside a folded group that the lane's row holds: rows 0,1,2,3 carry values 0,2,1,3
-__device__ __forceinline__ int fold_slot(int lane) {
-	const int row = lane >> 4;
-	return ((row & 1) << 1) | (row >> 1);
 }
 
 // single value (compiler-scheduled form; used off the hot path)

@@ -575,12 +575,14 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 
 // Wave-per-quadrant backward.  One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a tile and
 // walks the tile's list back to front in batches of 64 entries:
-//   1. each lane takes one list entry, loads its bounds and votes (ballot) whether the surfel can reach
-//      this block and is before the wave's last contributor -> compacted private work list;
-//   2. only the surviving records are gathered (5 lanes per 80-byte record) into LDS;
-//   3. the wave blends the survivors; per contributing surfel the 19 gradient values are reduced across
-//      the 64 pixels with fused DPP adds and parked in LDS by lane 63;
-//   4. the wave flushes the parked rows as 80-byte contiguous float atomics into acc[P][20].
+//   1. each lane takes one list entry, loads its cull record and votes (ballot) whether the surfel's footprint can
+//      reach this block and lies before the wave's last contributor -> compacted private work list;
+//   2. the wave differentiates the survivors one at a time; the record of the current one is wave-uniform and arrives
+//      through the scalar memory path into SGPRs (two buffers ping-pong), nothing is staged in LDS;
+//   3. per contributing surfel the 19 gradient values are reduced over each 16-lane row with exchange-type DPP
+//      (row_reduce_groups) and parked in the slab row of (hit, row);
+//   4. every S_SUB hits the wave adds the four row totals and flushes them as 80 contiguous bytes of float atomics per
+//      surfel into acc[P][20].
 // No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
 // threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
 __device__ __forceinline__ void
