@@ -88,11 +88,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev        # one rank per GPU on a full node; ranks share a GPU only in the gloo rehearsal below
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to rehearse N > 1 on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import gsr_synth as S
     import _gsr
