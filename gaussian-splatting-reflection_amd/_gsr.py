@@ -66,7 +66,9 @@ def _load():
     lib.gsr_deferred_reflection_forward.restype = c_int
     lib.gsr_deferred_reflection_forward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P]
     lib.gsr_deferred_reflection_backward.restype = c_int
-    lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P, P]
+    lib.gsr_deferred_reflection_scratch_floats.restype = c_size_t
+    lib.gsr_deferred_reflection_scratch_floats.argtypes = [c_uint32, c_int, c_int, c_int]
+    lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]
     lib.gsr_ssim_l1_forward.restype = c_int
     lib.gsr_ssim_l1_scratch_floats.restype = c_size_t
     lib.gsr_ssim_l1_scratch_floats.argtypes = [c_int, c_int, c_int]
@@ -98,7 +100,7 @@ lib = _load()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
+            "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",

@@ -3,9 +3,15 @@
 // LEFT_TOP_AS_ORIGIN branch) and gaussian_renderer/__init__.py:22-35,148,178-179,197-199 +
 // utils/general_utils.py:177-197 of the reference.  One thread per direction / pixel; the cubemap itself
 // (<= 4.7 MB at L = 256) lives in L2 / Infinity Cache, the streaming traffic is the per-pixel planes.
+#include <cstring>
 #include "gsr_internal.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace gsr {
+
+#define REFL_BAND 1024u   // texels per band of the binned reflection backward (12 KB of LDS, channel-planar)
+#define REFL_SPLIT 16     // workgroups per band
+
 
 // ----------------------------------------------------------------------------------------------
 // Face / uv selection (CME cubemapencoder.cu:147-187)
@@ -374,7 +380,8 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
                          const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
                          int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color, const float* __restrict__ g_nworld,
                          float* __restrict__ g_normal_view, float* __restrict__ g_base, float* __restrict__ g_strength,
-                         float* __restrict__ g_scratch, float* __restrict__ g_fail) {
+                         float* __restrict__ g_scratch, float* __restrict__ g_fail, float* __restrict__ entries, uint32_t* __restrict__ keys,
+                         uint32_t nbands) {
 	const size_t HW = (size_t)W * H;
 	const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
 	const size_t pix = gid >> 2;
@@ -446,6 +453,21 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 			cube_uv_backward(face, o.rx, o.ry, o.rz, lg0, lg1, grx, gry, grz);
 		}
 	}
+	// ---- binned path (entries != NULL): no atomics here.  Each (pixel, corner) becomes one 16-byte entry {g_r, g_g, g_b,
+	// texel id} — the quad's lanes 0..2 write their channel, lane 3 the texel id and the sort key (the cube-face band of
+	// the texel) — and gsr_deferred_reflection_backward sorts the entries by band and accumulates each band in LDS.
+	if (entries) {
+		if (live) {
+			const bool ok4[4] = {!fail, !fail, !fail, !fail && !s.is_vertex};
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const uint32_t t = ok4[k] ? (uint32_t)(((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) : 0u;
+				const size_t e = pix * 4 + k;
+				entries[e * 4 + ch] = ch < 3 ? (ok4[k] ? twg[k] : 0.f) : __uint_as_float(t);
+				if (ch == 3) keys[e] = ok4[k] ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
+			}
+		}
+	} else
 	// ---- texel adds.  Float atomics are priced per 64-byte memory-side request, and the two x-neighbours of a bilinear
 	// footprint are 16 bytes apart in the interleaved scratch.  Quads are paired (pixels A, B = quads 2j, 2j+1): in each
 	// of four rounds the eight lanes of a pair serve ONE pixel's row of the footprint — quad A's lanes the left texel,
@@ -499,6 +521,51 @@ __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* 
 	g_cubemap[(f * 3 + 2) * LL + r] += g.z;
 }
 
+// ---- binned accumulation of the texel gradients (see gsr_deferred_reflection_backward)
+// band boundaries in the sorted key array: ranges[b] = [first, last) entry of band b
+__global__ void __launch_bounds__(256) refl_band_ranges_kernel(size_t n, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t cur = keys[i];
+	if (i == 0) ranges[cur].x = 0;
+	else {
+		const uint32_t prev = keys[i - 1];
+		if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
+	}
+	if (i == n - 1) ranges[cur].y = (uint32_t)n;
+}
+// grid (REFL_SPLIT, nbands): workgroup (j, b) adds the j-th slice of band b's entries into an LDS copy of the band
+// (REFL_BAND texels x 4 floats = 32 KB) and then adds that copy to the interleaved scratch with contiguous atomics.
+__global__ void __launch_bounds__(256) refl_band_accumulate_kernel(const float4* __restrict__ entries, const uint2* __restrict__ ranges,
+                                                                   size_t ntex, float* __restrict__ g_scratch) {
+	__shared__ float acc[3][REFL_BAND];   // channel-planar: consecutive texels fall into consecutive LDS banks
+	const uint32_t b = blockIdx.y;
+	const uint2 r = ranges[b];
+	const uint32_t len = r.y - r.x;
+	if (len == 0) return;
+	const uint32_t per = (len + gridDim.x - 1) / gridDim.x;
+	const uint32_t lo = r.x + blockIdx.x * per, hi = min(r.y, lo + per);
+	if (lo >= hi) return;
+	for (int i = threadIdx.x; i < (int)REFL_BAND; i += 256) { acc[0][i] = 0.f; acc[1][i] = 0.f; acc[2][i] = 0.f; }
+	__syncthreads();
+	const uint32_t base = b * REFL_BAND;
+	for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+		const float4 e = entries[i];
+		const uint32_t t = __float_as_uint(e.w) - base;
+		atomicAdd(&acc[0][t], e.x);
+		atomicAdd(&acc[1][t], e.y);
+		atomicAdd(&acc[2][t], e.z);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < (int)REFL_BAND * 4; i += 256) {   // lane -> (texel, channel) of the interleaved staging buffer
+		const uint32_t t = (uint32_t)i >> 2, c = (uint32_t)i & 3u;
+		if (c < 3u && (size_t)base + t < ntex) {
+			const float v = acc[c][t];
+			if (v != 0.f) atomicAdd(g_scratch + ((size_t)base + t) * 4 + c, v);
+		}
+	}
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -544,11 +611,37 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
 	return 0;
 }
 
+// Scratch layout of the binned backward (floats): [texel staging ntex*4][keys_in n][keys_out n][entries_in 4n][entries_out 4n]
+// [band ranges 2*(nbands+1)][sort temp], n = 4 * H * W entries.
+struct ReflScratch {
+	size_t ntex, n, nbands, sort_bytes, total_floats;
+	int key_bits;
+};
+using ReflSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+static ReflScratch refl_scratch(uint32_t L, int width, int height) {
+	ReflScratch r;
+	r.ntex = (size_t)6 * L * L;
+	r.n = (size_t)width * height * 4;
+	r.nbands = (r.ntex + REFL_BAND - 1) / REFL_BAND;
+	r.key_bits = 1;
+	while (((size_t)1 << r.key_bits) <= r.nbands) r.key_bits++;   // keys take values 0..nbands
+	r.sort_bytes = 0;
+	(void)rocprim::radix_sort_pairs<ReflSortConfig>(nullptr, r.sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr,
+	                                                r.n, 0, r.key_bits, 0, false);
+	r.total_floats = r.ntex * 4 + 2 * r.n + 8 * r.n + 2 * (r.nbands + 1) + (r.sort_bytes + 3) / 4 + 128;   // + slack to align the sort temp
+	return r;
+}
+extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, int height, int binned) {
+	if (L == 0 || width <= 0 || height <= 0) return 0;
+	if (!binned) return (size_t)6 * L * L * 4;
+	return refl_scratch(L, width, height).total_floats;
+}
+
 extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                 const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                 const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                 float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
-                                                float* scratch, void* stream_) {
+                                                float* scratch, size_t scratch_floats, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
 	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
@@ -556,13 +649,40 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
-	const size_t ntex = (size_t)6 * L * L;
+	const ReflScratch rs = refl_scratch(L, width, height);
+	const size_t ntex = rs.ntex;
+	if (scratch_floats < ntex * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than 6*L*L*4 floats"); return GSR_E_INVALID; }
+	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 31);
 	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, ntex * 4 * sizeof(float), stream));
-	{ StageTimer st_(GSR_STAGE_REFL_BWD, stream);
-	deferred_refl_bwd_kernel<<<(unsigned)((HW * 4 + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
-	                                                                             (int)L, width, height, g_final, g_refl_color, g_normal_world,
-	                                                                             g_normal_view, g_base, g_strength, scratch, g_fail);
-	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, (int)L); }
+	StageTimer st_(GSR_STAGE_REFL_BWD, stream);
+	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
+	if (!binned) {
+		// texel gradients by float atomics straight from the pixel kernel (memory-side, ~2.5 requests per pixel)
+		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
+		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail, nullptr,
+		                                                  nullptr, 0u);
+	} else {
+		// binned: the pixel kernel stores one 16-byte entry per (pixel, corner); ONE radix pass orders the entries by the
+		// cube-face band of their texel (2048 texels = 32 KB of LDS); each band is accumulated in LDS by REFL_SPLIT
+		// workgroups and added to the staging buffer with contiguous atomics.  Float atomics per launch drop from ~25 M
+		// scattered dwords to ~6 M contiguous ones.
+		uint32_t* keys_in = reinterpret_cast<uint32_t*>(scratch + ntex * 4);
+		uint32_t* keys_out = keys_in + rs.n;
+		float4* ent_in = reinterpret_cast<float4*>(keys_out + rs.n);
+		float4* ent_out = ent_in + rs.n;
+		uint2* ranges = reinterpret_cast<uint2*>(ent_out + rs.n);
+		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(ranges + (rs.nbands + 1)) + 255) & ~(uintptr_t)255);
+		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
+		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail,
+		                                                  reinterpret_cast<float*>(ent_in), keys_in, (uint32_t)rs.nbands);
+		size_t sb = rs.sort_bytes;
+		GSR_HIP_CHECK(rocprim::radix_sort_pairs<ReflSortConfig>(sort_temp, sb, keys_in, keys_out, ent_in, ent_out, rs.n, 0u, (unsigned)rs.key_bits,
+		                                                        stream, false));
+		GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, (rs.nbands + 1) * sizeof(uint2), stream));
+		refl_band_ranges_kernel<<<(unsigned)((rs.n + 255) / 256), 256, 0, stream>>>(rs.n, keys_out, ranges);
+		refl_band_accumulate_kernel<<<dim3(REFL_SPLIT, (unsigned)rs.nbands), 256, 0, stream>>>(ent_out, ranges, ntex, scratch);
+	}
+	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, (int)L);
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }

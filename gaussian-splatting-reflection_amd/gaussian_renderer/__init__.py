@@ -87,6 +87,10 @@ def _cam_block(world_view_transform, HWK, R, T):
     return cam
 
 
+# True: sort-and-accumulate-in-LDS path of the reflection backward (needs ~84 bytes of scratch per pixel); False: float atomics
+REFLECTION_BACKWARD_BINNED = True
+
+
 class _DeferredReflection(torch.autograd.Function):
     @staticmethod
     def forward(ctx, normal_view, base_color, refl_strength, cubemap, fail_value, cam):
@@ -114,11 +118,12 @@ class _DeferredReflection(torch.autograd.Function):
         g_normal_world = None if g_normal_world is None else g_normal_world.float().contiguous()
         g_nv, g_base, g_s = torch.empty_like(nv), torch.empty_like(bc), torch.empty_like(rs)
         g_cm, g_fail = torch.zeros_like(cm), torch.zeros_like(fv)
-        scratch = torch.empty(6 * cm.shape[2] * cm.shape[2] * 4, dtype=torch.float32, device=cm.device)
+        n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=cm.device)
         with torch.cuda.device(nv.device):
             check(lib.gsr_deferred_reflection_backward(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(g_final),
                                                        ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base), ptr(g_s), ptr(g_cm),
-                                                       ptr(g_fail), ptr(scratch), stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+                                                       ptr(g_fail), ptr(scratch), n_scratch, stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
         return g_nv, g_base, g_s, g_cm, g_fail, None
 
 

@@ -150,15 +150,17 @@ int gsr_deferred_reflection_forward(const float* normal_view, const float* base_
                                     float* out_normal_world, void* stream);
 /*   Upstream grads: g_final [3,H,W] (required), g_refl_color, g_normal_world may be NULL.
  *   Outputs: g_normal_view [3,H,W], g_base [3,H,W], g_strength [H,W] fully written; g_cubemap,
- *   g_fail accumulated into.  scratch: caller-provided device buffer of 6*L*L*4 floats (contents ignored;
- *   used as a channel-interleaved staging area for the texel-gradient atomics). */
+ *   g_fail accumulated into.  scratch: caller-provided device buffer of `scratch_floats` floats (contents ignored).
+ *   With at least gsr_deferred_reflection_scratch_floats(L, W, H, 0) = 6*L*L*4 floats the texel gradients are added
+ *   with float atomics from the pixel kernel; with gsr_deferred_reflection_scratch_floats(L, W, H, 1) floats
+ *   (~84 bytes per pixel) the binned path runs instead: one 16-byte entry per (pixel, bilinear corner), one radix
+ *   pass by cube-face band, per-band accumulation in LDS. */
+size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, int height, int binned);
 int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength,
                                      const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
                                      int width, int height, const float* g_final, const float* g_refl_color,
-                                     const float* g_normal_world, float* g_normal_view, float* g_base,
-                                     float* g_strength, float* g_cubemap, float* g_fail, float* scratch,
-                                     void* stream);
-
+                                     const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
+                                     float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step passes around the rasterizer.

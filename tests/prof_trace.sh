@@ -7,12 +7,12 @@ python - <<'PY'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/prof_tr/kt/kt_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'surfel_preprocess_kernel' in r['Kernel_Name']]
-a=idx[-8]; 
+idx=[i for i,r in enumerate(rows) if 'deferred_refl_bwd_kernel' in r['Kernel_Name']]
+a=idx[-3]-2
 t0=int(rows[a]['Start_Timestamp']); prev=t0
-for r in rows[a:a+60]:
+for r in rows[a:a+30]:
     s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
-    print(f"{(s-t0)/1e3:9.1f}us gap {(s-prev)/1e3:7.1f} dur {(e-s)/1e3:8.1f}  {r['Kernel_Name'][:100]}")
+    print(f"{(s-t0)/1e3:9.1f}us gap {(s-prev)/1e3:7.1f} dur {(e-s)/1e3:8.1f}  {r['Kernel_Name'][:90]}")
     prev=e
-    if 'surfel_render_fwd' in r['Kernel_Name']: break
+    if 'surfel_render_bwd' in r['Kernel_Name']: break
 PY

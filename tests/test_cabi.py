@@ -41,7 +41,8 @@ def test_ctypes_signatures_match_header(hip_lib_built):
             return ctypes.POINTER(_gsr.GatherGroup)
         if "*" in arg:
             return ctypes.c_char_p if (arg.startswith("const char") and "uint8" not in arg) else ctypes.c_void_p
-        for pre, t in (("float", ctypes.c_float), ("uint32_t", ctypes.c_uint32), ("uint64_t", ctypes.c_uint64), ("int", ctypes.c_int)):
+        for pre, t in (("float", ctypes.c_float), ("uint32_t", ctypes.c_uint32), ("uint64_t", ctypes.c_uint64), ("size_t", ctypes.c_size_t),
+                       ("int", ctypes.c_int)):
             if arg.startswith(pre):
                 return t
         raise ValueError(arg)
