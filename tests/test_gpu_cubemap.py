@@ -105,8 +105,12 @@ def _reference_chain(normal_view, base, strength, cubemap, fail, cam, W, H):
     return final, col, rn.permute(2, 0, 1)
 
 
-def test_fused_deferred_reflection_vs_reference_chain():
+@pytest.mark.parametrize("binned", [True, False])
+def test_fused_deferred_reflection_vs_reference_chain(binned, monkeypatch):
+    """Both backward paths of the fused op: texel gradients binned by cube-face band (default) and by float atomics."""
+    import gaussian_renderer
     from gaussian_renderer import deferred_reflection
+    monkeypatch.setattr(gaussian_renderer, "REFLECTION_BACKWARD_BINNED", binned)
     W, H, L = 160, 96, 16
     cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
     g = torch.Generator().manual_seed(11)
