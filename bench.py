@@ -12,6 +12,8 @@ with ONE RCCL all-reduce over a flat pre-packed buffer.  value 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel (tile-render backward): algorithmic bytes / hipEvent-measured launch time
   cpu_baseline  the CPU oracle (oracle/, "port") timed on this host on one full C3 step
+and, beside them, `full_train_step`: the same step + L1/SSIM loss + gradient all-reduce + fused Adam (secondary figure,
+never `value`; --no-full-step skips it).
 """
 import argparse
 import json
