@@ -304,6 +304,7 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // touched surfel.  The wave stops as soon as ITS 64 pixels are saturated: no workgroup barriers, no waiting
 // for the other three quadrants (the reference synchronises the 256 threads of a tile twice per batch).
 #define S_WBATCH 64
+#define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
 #define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 __global__ void __launch_bounds__(64)
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
@@ -345,7 +346,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		if (hit) {
 			id = point_list[range.x + (uint32_t)(base + lane)];
 			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - CULL_PAD, qx1 + CULL_PAD, qy0 - CULL_PAD, qy1 + CULL_PAD);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
@@ -631,7 +632,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		if (hit) {
 			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
 			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - CULL_PAD, qx1 + CULL_PAD, qy0 - CULL_PAD, qy1 + CULL_PAD);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
