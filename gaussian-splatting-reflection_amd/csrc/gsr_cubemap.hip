@@ -457,15 +457,28 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 	// texel id} — the quad's lanes 0..2 write their channel, lane 3 the texel id and the sort key (the cube-face band of
 	// the texel) — and gsr_deferred_reflection_backward sorts the entries by band and accumulates each band in LDS.
 	if (entries) {
+		// 4x4 transpose inside the quad (lane = channel, register = corner  ->  lane = corner, xyz = channels) with quad
+		// broadcasts, so every lane stores one whole 16-byte entry and a wave writes 1 KB contiguously instead of four
+		// instructions that each touch a quarter of sixteen 64-byte lines
+#define GSR_QUAD_BCAST(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true))
+		// all four broadcasts run on the whole wave; the select by the lane's corner comes afterwards
+#define GSR_QUAD_COLUMN(name, ctrl)                                                                                        \
+		const float name##0 = GSR_QUAD_BCAST(twg[0], ctrl), name##1 = GSR_QUAD_BCAST(twg[1], ctrl),                          \
+		            name##2 = GSR_QUAD_BCAST(twg[2], ctrl), name##3 = GSR_QUAD_BCAST(twg[3], ctrl);                          \
+		const float name = ch == 0 ? name##0 : ch == 1 ? name##1 : ch == 2 ? name##2 : name##3;
+		GSR_QUAD_COLUMN(e_r, 0x00)
+		GSR_QUAD_COLUMN(e_g, 0x55)
+		GSR_QUAD_COLUMN(e_b, 0xAA)
+#undef GSR_QUAD_COLUMN
+#undef GSR_QUAD_BCAST
 		if (live) {
-			const bool ok4[4] = {!fail, !fail, !fail, !fail && !s.is_vertex};
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const uint32_t t = ok4[k] ? (uint32_t)(((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) : 0u;
-				const size_t e = pix * 4 + k;
-				entries[e * 4 + ch] = ch < 3 ? (ok4[k] ? twg[k] : 0.f) : __uint_as_float(t);
-				if (ch == 3) keys[e] = ok4[k] ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
-			}
+			const bool ok = !fail && !(ch == 3 && s.is_vertex);   // this lane's corner exists
+			const int sf = ch == 0 ? s.f[0] : ch == 1 ? s.f[1] : ch == 2 ? s.f[2] : s.f[3];
+			const int sy = ch == 0 ? s.y[0] : ch == 1 ? s.y[1] : ch == 2 ? s.y[2] : s.y[3];
+			const int sx = ch == 0 ? s.x[0] : ch == 1 ? s.x[1] : ch == 2 ? s.x[2] : s.x[3];
+			const uint32_t t = ok ? (uint32_t)(((size_t)sf * L + sy) * L + sx) : 0u;
+			reinterpret_cast<float4*>(entries)[gid] = make_float4(ok ? e_r : 0.f, ok ? e_g : 0.f, ok ? e_b : 0.f, __uint_as_float(t));
+			keys[gid] = ok ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
 		}
 	} else
 	// ---- texel adds.  Float atomics are priced per 64-byte memory-side request, and the two x-neighbours of a bilinear
@@ -508,6 +521,120 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 	if (chan) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
 }
 
+// The same backward for the binned path, one lane per pixel: nothing here needs the four lanes of the quad version (they
+// exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  Each pixel emits four
+// 16-byte entries {g_r, g_g, g_b, texel id} (texel id ~0 = corner absent); a wave parks its 256 entries in LDS — the
+// corner slot xor-ed with the pixel's low bits, so that four neighbouring lanes fill one 64-byte run; the order of a
+// pixel's corners in the entry list is irrelevant — and writes them and their band keys back fully coalesced.
+__global__ void __launch_bounds__(256)
+deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
+                                 const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L,
+                                 int W, int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color,
+                                 const float* __restrict__ g_nworld, float* __restrict__ g_normal_view, float* __restrict__ g_base,
+                                 float* __restrict__ g_strength, float* __restrict__ g_fail, float4* __restrict__ entries,
+                                 uint32_t* __restrict__ keys, uint32_t nbands) {
+	__shared__ float4 s_ent[256 * 4];
+	const size_t HW = (size_t)W * H;
+	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const bool live = pix < HW;
+	const size_t p = live ? pix : 0;
+	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
+	ReflPixel o;
+	refl_pixel(cam, normal_view[p], normal_view[HW + p], normal_view[2 * HW + p], px, py, o);
+	const bool fail = (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f);
+	Seamless s;
+	int face = 0;
+	s.kx = 0; s.ky = 0; s.flag = 0; s.is_vertex = false;
+	if (!fail) {
+		float u, v;
+		cube_uv(o.rx, o.ry, o.rz, u, v, face);
+		seamless_index(face, L, u, v, s);
+	}
+	const float sv = strength[p];
+	float graw[3] = {0.f, 0.f, 0.f};
+	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		float cval, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+		if (fail) cval = fail_value[c];
+		else {
+			v00 = cubemap[texel(s.f[0], c, s.y[0], s.x[0], 3, L)];
+			v01 = cubemap[texel(s.f[1], c, s.y[1], s.x[1], 3, L)];
+			v10 = cubemap[texel(s.f[2], c, s.y[2], s.x[2], 3, L)];
+			v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], c, s.y[3], s.x[3], 3, L)];
+			cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
+		}
+		const float rc = sigmoidf_(cval);
+		const float gf = g_final[c * HW + p];
+		const float b = base[c * HW + p];
+		if (live) g_base[c * HW + p] = (1 - sv) * gf;
+		gs += gf * (rc - b);
+		float gc = sv * gf;
+		if (g_refl_color) gc += g_refl_color[c * HW + p];
+		graw[c] = gc * rc * (1 - rc);   // sigmoid'
+		if (fail) {
+			if (live) atomicAdd(g_fail + c, graw[c]);
+		} else {
+			float lg0 = (1 - s.ky) * (v01 - v00) + s.ky * (v11 - v10);
+			float lg1 = (1 - s.kx) * (v10 - v00) + s.kx * (v11 - v01);
+			lg0 *= 0.5f * (float)L * graw[c];
+			lg1 *= 0.5f * (float)L * graw[c];
+			if (s.flag & 1) lg0 = -lg0;
+			if (s.flag & 4) lg1 = -lg1;
+			lg1 = -lg1;
+			float a, bb, cc;
+			cube_uv_backward(face, o.rx, o.ry, o.rz, lg0, lg1, a, bb, cc);
+			grx += a; gry += bb; grz += cc;
+		}
+	}
+	// ---- entries: bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
+	{
+		const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
+		const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const bool ok = live && !fail && !(k == 3 && s.is_vertex);
+			const uint32_t t = ok ? (uint32_t)(((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) : 0xFFFFFFFFu;
+			const float wk = ok ? w4[k] : 0.f;
+			s_ent[threadIdx.x * 4 + (k ^ (threadIdx.x & 3))] = make_float4(wk * graw[0], wk * graw[1], wk * graw[2], __uint_as_float(t));
+		}
+	}
+	__syncthreads();
+	{
+		const size_t n = HW * 4;
+		const size_t wave_base = ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;   // first entry of this wave's 64 pixels
+		const int lane = threadIdx.x & 63;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const size_t e = wave_base + (size_t)(j * 64 + lane);
+			if (e < n) {
+				float4 v = s_ent[(threadIdx.x & ~63) * 4 + j * 64 + lane];
+				const uint32_t t = __float_as_uint(v.w);
+				const bool ok = t != 0xFFFFFFFFu;
+				v.w = __uint_as_float(ok ? t : 0u);
+				entries[e] = v;
+				keys[e] = ok ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
+			}
+		}
+	}
+	if (!live) return;
+	g_strength[p] = gs;
+	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
+	const float grn = grx * o.nx + gry * o.ny + grz * o.nz;
+	float gnx = -2.f * (o.dn * grx + grn * o.dx);
+	float gny = -2.f * (o.dn * gry + grn * o.dy);
+	float gnz = -2.f * (o.dn * grz + grn * o.dz);
+	if (g_nworld) { gnx += g_nworld[p]; gny += g_nworld[HW + p]; gnz += g_nworld[2 * HW + p]; }
+	const float inv = 1.0f / (o.len + 1e-6f);
+	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
+	if (o.len > 0.f) {
+		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv / o.len;
+		gwx -= o.nwx * k; gwy -= o.nwy * k; gwz -= o.nwz * k;
+	}
+#pragma unroll
+	for (int c = 0; c < 3; c++) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
+}
+
 // scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] +=
 __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap, int L) {
 	const size_t n = (size_t)6 * L * L;
@@ -538,7 +665,10 @@ __global__ void __launch_bounds__(256) refl_band_ranges_kernel(size_t n, const u
 // (REFL_BAND texels x 4 floats = 32 KB) and then adds that copy to the interleaved scratch with contiguous atomics.
 __global__ void __launch_bounds__(256) refl_band_accumulate_kernel(const float4* __restrict__ entries, const uint2* __restrict__ ranges,
                                                                    size_t ntex, float* __restrict__ g_scratch) {
-	__shared__ float acc[3][REFL_BAND];   // channel-planar: consecutive texels fall into consecutive LDS banks
+	// channel-planar: consecutive texels fall into consecutive LDS banks.  (Skewing the texel rows so that the four
+	// corners of a footprint fall into four different banks changes nothing: the kernel runs at the LDS float-atomic rate,
+	// ~4 clocks per lane.)
+	__shared__ float acc[3][REFL_BAND];
 	const uint32_t b = blockIdx.y;
 	const uint2 r = ranges[b];
 	const uint32_t len = r.y - r.x;
@@ -672,9 +802,10 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		float4* ent_out = ent_in + rs.n;
 		uint2* ranges = reinterpret_cast<uint2*>(ent_out + rs.n);
 		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(ranges + (rs.nbands + 1)) + 255) & ~(uintptr_t)255);
-		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
-		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail,
-		                                                  reinterpret_cast<float*>(ent_in), keys_in, (uint32_t)rs.nbands);
+		deferred_refl_bwd_entries_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
+		                                                                                (int)L, width, height, g_final, g_refl_color, g_normal_world,
+		                                                                                g_normal_view, g_base, g_strength, g_fail, ent_in, keys_in,
+		                                                                                (uint32_t)rs.nbands);
 		size_t sb = rs.sort_bytes;
 		GSR_HIP_CHECK(rocprim::radix_sort_pairs<ReflSortConfig>(sort_temp, sb, keys_in, keys_out, ent_in, ent_out, rs.n, 0u, (unsigned)rs.key_bits,
 		                                                        stream, false));

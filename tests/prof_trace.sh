@@ -7,7 +7,7 @@ python - <<'PY'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/prof_tr/kt/kt_kernel_trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'deferred_refl_bwd_kernel' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'deferred_refl_bwd' in r['Kernel_Name']]
 a=idx[-3]-2
 t0=int(rows[a]['Start_Timestamp']); prev=t0
 for r in rows[a:a+30]:
