@@ -6,11 +6,10 @@
 #include <cstring>
 #include "gsr_internal.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace gsr {
 
-#define REFL_BAND 1024u   // texels per band of the binned reflection backward (12 KB of LDS, channel-planar)
-#define REFL_SPLIT 16     // workgroups per band
 
 
 // ----------------------------------------------------------------------------------------------
@@ -380,8 +379,7 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
                          const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
                          int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color, const float* __restrict__ g_nworld,
                          float* __restrict__ g_normal_view, float* __restrict__ g_base, float* __restrict__ g_strength,
-                         float* __restrict__ g_scratch, float* __restrict__ g_fail, float* __restrict__ entries, uint32_t* __restrict__ keys,
-                         uint32_t nbands) {
+                         float* __restrict__ g_scratch, float* __restrict__ g_fail) {
 	const size_t HW = (size_t)W * H;
 	const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
 	const size_t pix = gid >> 2;
@@ -453,34 +451,6 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 			cube_uv_backward(face, o.rx, o.ry, o.rz, lg0, lg1, grx, gry, grz);
 		}
 	}
-	// ---- binned path (entries != NULL): no atomics here.  Each (pixel, corner) becomes one 16-byte entry {g_r, g_g, g_b,
-	// texel id} — the quad's lanes 0..2 write their channel, lane 3 the texel id and the sort key (the cube-face band of
-	// the texel) — and gsr_deferred_reflection_backward sorts the entries by band and accumulates each band in LDS.
-	if (entries) {
-		// 4x4 transpose inside the quad (lane = channel, register = corner  ->  lane = corner, xyz = channels) with quad
-		// broadcasts, so every lane stores one whole 16-byte entry and a wave writes 1 KB contiguously instead of four
-		// instructions that each touch a quarter of sixteen 64-byte lines
-#define GSR_QUAD_BCAST(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true))
-		// all four broadcasts run on the whole wave; the select by the lane's corner comes afterwards
-#define GSR_QUAD_COLUMN(name, ctrl)                                                                                        \
-		const float name##0 = GSR_QUAD_BCAST(twg[0], ctrl), name##1 = GSR_QUAD_BCAST(twg[1], ctrl),                          \
-		            name##2 = GSR_QUAD_BCAST(twg[2], ctrl), name##3 = GSR_QUAD_BCAST(twg[3], ctrl);                          \
-		const float name = ch == 0 ? name##0 : ch == 1 ? name##1 : ch == 2 ? name##2 : name##3;
-		GSR_QUAD_COLUMN(e_r, 0x00)
-		GSR_QUAD_COLUMN(e_g, 0x55)
-		GSR_QUAD_COLUMN(e_b, 0xAA)
-#undef GSR_QUAD_COLUMN
-#undef GSR_QUAD_BCAST
-		if (live) {
-			const bool ok = !fail && !(ch == 3 && s.is_vertex);   // this lane's corner exists
-			const int sf = ch == 0 ? s.f[0] : ch == 1 ? s.f[1] : ch == 2 ? s.f[2] : s.f[3];
-			const int sy = ch == 0 ? s.y[0] : ch == 1 ? s.y[1] : ch == 2 ? s.y[2] : s.y[3];
-			const int sx = ch == 0 ? s.x[0] : ch == 1 ? s.x[1] : ch == 2 ? s.x[2] : s.x[3];
-			const uint32_t t = ok ? (uint32_t)(((size_t)sf * L + sy) * L + sx) : 0u;
-			reinterpret_cast<float4*>(entries)[gid] = make_float4(ok ? e_r : 0.f, ok ? e_g : 0.f, ok ? e_b : 0.f, __uint_as_float(t));
-			keys[gid] = ok ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
-		}
-	} else
 	// ---- texel adds.  Float atomics are priced per 64-byte memory-side request, and the two x-neighbours of a bilinear
 	// footprint are 16 bytes apart in the interleaved scratch.  Quads are paired (pixels A, B = quads 2j, 2j+1): in each
 	// of four rounds the eight lanes of a pair serve ONE pixel's row of the footprint — quad A's lanes the left texel,
@@ -522,18 +492,22 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 }
 
 // The same backward for the binned path, one lane per pixel: nothing here needs the four lanes of the quad version (they
-// exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  Each pixel emits four
-// 16-byte entries {g_r, g_g, g_b, texel id} (texel id ~0 = corner absent); a wave parks its 256 entries in LDS — the
-// corner slot xor-ed with the pixel's low bits, so that four neighbouring lanes fill one 64-byte run; the order of a
-// pixel's corners in the entry list is irrelevant — and writes them and their band keys back fully coalesced.
+// exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  A pixel whose bilinear
+// footprint lies inside one cube face (all but the half-texel rim, ~2/L of the pixels) emits ONE record {g_r, g_g, g_b, kx,
+// ky} plus the sort key "texel id of the upper-left corner": the other corners are t+1, t+L, t+L+1 and the four weights
+// follow from (kx, ky).  Rim pixels (footprints that wrap onto a neighbouring face, cube vertices) add their corners to
+// the staging buffer directly.
+struct alignas(32) ReflFootprint {
+	float g[3], kx, ky;   // 20 bytes used; padded so that a record never straddles a 32-byte sector when it is gathered
+	float pad[3];
+};
 __global__ void __launch_bounds__(256)
 deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
                                  const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L,
                                  int W, int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color,
                                  const float* __restrict__ g_nworld, float* __restrict__ g_normal_view, float* __restrict__ g_base,
-                                 float* __restrict__ g_strength, float* __restrict__ g_fail, float4* __restrict__ entries,
-                                 uint32_t* __restrict__ keys, uint32_t nbands) {
-	__shared__ float4 s_ent[256 * 4];
+                                 float* __restrict__ g_strength, float* __restrict__ g_fail, float* __restrict__ g_scratch,
+                                 ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, uint32_t no_key) {
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	const bool live = pix < HW;
@@ -587,37 +561,30 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 			grx += a; gry += bb; grz += cc;
 		}
 	}
-	// ---- entries: bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
+	if (!live) return;
 	{
-		const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
-		const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const bool ok = live && !fail && !(k == 3 && s.is_vertex);
-			const uint32_t t = ok ? (uint32_t)(((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) : 0xFFFFFFFFu;
-			const float wk = ok ? w4[k] : 0.f;
-			s_ent[threadIdx.x * 4 + (k ^ (threadIdx.x & 3))] = make_float4(wk * graw[0], wk * graw[1], wk * graw[2], __uint_as_float(t));
+		// flag == 0 already implies the unclamped 2x2 block; the corner test keeps the record format honest regardless
+		const bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
+		const uint32_t t00 = (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
+		if (interior) {
+			float* f = reinterpret_cast<float*>(footprints + pix);
+			*reinterpret_cast<float4*>(f) = make_float4(graw[0], graw[1], graw[2], s.kx);
+			f[4] = s.ky;
 		}
-	}
-	__syncthreads();
-	{
-		const size_t n = HW * 4;
-		const size_t wave_base = ((size_t)blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;   // first entry of this wave's 64 pixels
-		const int lane = threadIdx.x & 63;
+		keys[pix] = interior ? t00 : no_key;
+		if (!fail && !interior) {
+			// rim: bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
+			const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
+			const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
-			const size_t e = wave_base + (size_t)(j * 64 + lane);
-			if (e < n) {
-				float4 v = s_ent[(threadIdx.x & ~63) * 4 + j * 64 + lane];
-				const uint32_t t = __float_as_uint(v.w);
-				const bool ok = t != 0xFFFFFFFFu;
-				v.w = __uint_as_float(ok ? t : 0u);
-				entries[e] = v;
-				keys[e] = ok ? t / REFL_BAND : nbands;   // nbands = the "nothing to add" bin
+			for (int k = 0; k < 4; k++) {
+				if (k == 3 && s.is_vertex) continue;
+				float* dst = g_scratch + ((((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) << 2);
+#pragma unroll
+				for (int c = 0; c < 3; c++) atomicAdd(dst + c, w4[k] * graw[c]);
 			}
 		}
 	}
-	if (!live) return;
 	g_strength[p] = gs;
 	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
 	const float grn = grx * o.nx + gry * o.ny + grz * o.nz;
@@ -648,50 +615,95 @@ __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* 
 	g_cubemap[(f * 3 + 2) * LL + r] += g.z;
 }
 
-// ---- binned accumulation of the texel gradients (see gsr_deferred_reflection_backward)
-// band boundaries in the sorted key array: ranges[b] = [first, last) entry of band b
-__global__ void __launch_bounds__(256) refl_band_ranges_kernel(size_t n, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
-	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t cur = keys[i];
-	if (i == 0) ranges[cur].x = 0;
-	else {
-		const uint32_t prev = keys[i - 1];
-		if (cur != prev) { ranges[prev].y = (uint32_t)i; ranges[cur].x = (uint32_t)i; }
-	}
-	if (i == n - 1) ranges[cur].y = (uint32_t)n;
-}
-// grid (REFL_SPLIT, nbands): workgroup (j, b) adds the j-th slice of band b's entries into an LDS copy of the band
-// (REFL_BAND texels x 4 floats = 32 KB) and then adds that copy to the interleaved scratch with contiguous atomics.
-__global__ void __launch_bounds__(256) refl_band_accumulate_kernel(const float4* __restrict__ entries, const uint2* __restrict__ ranges,
-                                                                   size_t ntex, float* __restrict__ g_scratch) {
-	// channel-planar: consecutive texels fall into consecutive LDS banks.  (Skewing the texel rows so that the four
-	// corners of a footprint fall into four different banks changes nothing: the kernel runs at the LDS float-atomic rate,
-	// ~4 clocks per lane.)
-	__shared__ float acc[3][REFL_BAND];
-	const uint32_t b = blockIdx.y;
-	const uint2 r = ranges[b];
-	const uint32_t len = r.y - r.x;
-	if (len == 0) return;
-	const uint32_t per = (len + gridDim.x - 1) / gridDim.x;
-	const uint32_t lo = r.x + blockIdx.x * per, hi = min(r.y, lo + per);
-	if (lo >= hi) return;
-	for (int i = threadIdx.x; i < (int)REFL_BAND; i += 256) { acc[0][i] = 0.f; acc[1][i] = 0.f; acc[2][i] = 0.f; }
+// ---- accumulation of the footprints (see gsr_deferred_reflection_backward).  (texel id, pixel) pairs arrive sorted by
+// texel id, so equal texels are adjacent and a workgroup's REFL_CHUNK * 256 records cover a narrow range of texels:
+//   * every thread gathers the records of REFL_CHUNK consecutive pairs, sums the twelve (corner, channel) contributions
+//     of a run of equal texels in registers and, when the texel changes, adds them to an LDS window of REFL_WIN texels
+//     that starts at the workgroup's first texel (global atomics only for the rare texel beyond the window);
+//   * the touched part of the window then goes to the staging buffer with contiguous atomics.
+// LDS float atomics run at ~4 clocks per lane and memory-side ones at ~30 G/s, so the counts are what matters: per pixel
+// ~12 / mean-run-length LDS adds (was 12) and per launch ~3 x distinct texels global adds (was 12 x pixels).
+#define REFL_CHUNK 8
+#define REFL_WIN 4096u
+__global__ void __launch_bounds__(256) refl_run_combine_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ pix_sorted,
+                                                               const ReflFootprint* __restrict__ footprints, size_t n, uint32_t L, uint32_t no_key,
+                                                               float* __restrict__ g_scratch) {
+	__shared__ float win[3][REFL_WIN];
+	__shared__ uint32_t s_hi;
+	const size_t wg0 = (size_t)blockIdx.x * 256 * REFL_CHUNK;   // < n by the grid size
+	const uint32_t t_lo = keys_sorted[wg0];
+	if (t_lo == no_key) return;   // the "nothing to add" pairs sort to the end: nothing left for this workgroup
+	// only the part of the window this workgroup can reach is cleared: its last texel plus the footprint (L + 1 further)
+	const size_t wg_last = min(n, wg0 + (size_t)256 * REFL_CHUNK) - 1;
+	const uint32_t t_hi = keys_sorted[wg_last];
+	const uint32_t reach = t_hi == no_key ? REFL_WIN : min(REFL_WIN, t_hi - t_lo + L + 2u);
+	for (uint32_t i = threadIdx.x; i < reach; i += 256) { win[0][i] = 0.f; win[1][i] = 0.f; win[2][i] = 0.f; }
+	if (threadIdx.x == 0) s_hi = 0u;
 	__syncthreads();
-	const uint32_t base = b * REFL_BAND;
-	for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-		const float4 e = entries[i];
-		const uint32_t t = __float_as_uint(e.w) - base;
-		atomicAdd(&acc[0][t], e.x);
-		atomicAdd(&acc[1][t], e.y);
-		atomicAdd(&acc[2][t], e.z);
+
+	const size_t i0 = wg0 + (size_t)threadIdx.x * REFL_CHUNK;
+	uint32_t key[REFL_CHUNK];
+	float4 ga[REFL_CHUNK];
+	float gky[REFL_CHUNK];
+#pragma unroll
+	for (int j = 0; j < REFL_CHUNK; j++) key[j] = i0 + j < n ? keys_sorted[i0 + j] : no_key;
+#pragma unroll
+	for (int j = 0; j < REFL_CHUNK; j++) {
+		ga[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+		gky[j] = 0.f;
+		if (key[j] != no_key) {
+			const float* f = reinterpret_cast<const float*>(footprints + pix_sorted[i0 + j]);
+			ga[j] = *reinterpret_cast<const float4*>(f);
+			gky[j] = f[4];
+		}
 	}
+	float acc[4][3];
+	uint32_t cur = no_key, hi = 0u;
+	auto flush = [&]() {
+		if (cur == no_key) return;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t rel = cur - t_lo + (uint32_t)(k & 1) + (uint32_t)(k >> 1) * L;
+			if (rel < REFL_WIN) {
+				hi = max(hi, rel);
+#pragma unroll
+				for (int c = 0; c < 3; c++)
+					if (acc[k][c] != 0.f) atomicAdd(&win[c][rel], acc[k][c]);
+			} else {
+				float* dst = g_scratch + (((size_t)t_lo + rel) << 2);
+#pragma unroll
+				for (int c = 0; c < 3; c++)
+					if (acc[k][c] != 0.f) atomicAdd(dst + c, acc[k][c]);
+			}
+		}
+	};
+#pragma unroll
+	for (int j = 0; j < REFL_CHUNK; j++) {
+		if (key[j] != no_key) {
+			if (key[j] != cur) {
+				flush();
+				cur = key[j];
+#pragma unroll
+				for (int k = 0; k < 4; k++) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
+			}
+			const float kx = ga[j].w, ky = gky[j];
+			const float w4[4] = {(1 - ky) * (1 - kx), (1 - ky) * kx, ky * (1 - kx), ky * kx};
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				acc[k][0] += w4[k] * ga[j].x; acc[k][1] += w4[k] * ga[j].y; acc[k][2] += w4[k] * ga[j].z;
+			}
+		}
+	}
+	flush();
+	if (hi != 0u) atomicMax(&s_hi, hi);
 	__syncthreads();
-	for (int i = threadIdx.x; i < (int)REFL_BAND * 4; i += 256) {   // lane -> (texel, channel) of the interleaved staging buffer
-		const uint32_t t = (uint32_t)i >> 2, c = (uint32_t)i & 3u;
-		if (c < 3u && (size_t)base + t < ntex) {
-			const float v = acc[c][t];
-			if (v != 0.f) atomicAdd(g_scratch + ((size_t)base + t) * 4 + c, v);
+	const uint32_t top = s_hi;
+	for (uint32_t i = threadIdx.x; i <= top; i += 256) {
+		float* dst = g_scratch + (((size_t)t_lo + i) << 2);
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			const float v = win[c][i];
+			if (v != 0.f) atomicAdd(dst + c, v);
 		}
 	}
 }
@@ -741,24 +753,35 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
 	return 0;
 }
 
-// Scratch layout of the binned backward (floats): [texel staging ntex*4][keys_in n][keys_out n][entries_in 4n][entries_out 4n]
-// [band ranges 2*(nbands+1)][sort temp], n = 4 * H * W entries.
+// Scratch layout of the binned backward (floats): [texel staging ntex*4][footprints 8n][keys_in n][keys_out n][pixels_out n]
+// [sort temp], n = H * W.
 struct ReflScratch {
-	size_t ntex, n, nbands, sort_bytes, total_floats;
+	size_t ntex, n, sort_bytes, total_floats;
 	int key_bits;
 };
-using ReflSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+template <unsigned Bits>
+using ReflSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, Bits,
+                                                                                      rocprim::block_radix_rank_algorithm::match>,
+                                                  65536>;
+// 17-bit texel ids at L = 128, 19-bit at L = 256: two passes with 9- or 10-bit digits instead of three with 8
+static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream) {
+	rocprim::counting_iterator<uint32_t> pix_in(0);
+	if (key_bits > 16 && key_bits <= 18)
+		return rocprim::radix_sort_pairs<ReflSortConfig<9>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+	if (key_bits > 18 && key_bits <= 20)
+		return rocprim::radix_sort_pairs<ReflSortConfig<10>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+	return rocprim::radix_sort_pairs<ReflSortConfig<8>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+}
 static ReflScratch refl_scratch(uint32_t L, int width, int height) {
 	ReflScratch r;
 	r.ntex = (size_t)6 * L * L;
-	r.n = (size_t)width * height * 4;
-	r.nbands = (r.ntex + REFL_BAND - 1) / REFL_BAND;
+	r.n = (size_t)width * height;
 	r.key_bits = 1;
-	while (((size_t)1 << r.key_bits) <= r.nbands) r.key_bits++;   // keys take values 0..nbands
+	while (((size_t)1 << r.key_bits) <= r.ntex) r.key_bits++;   // keys take values 0..ntex (ntex = nothing to add)
 	r.sort_bytes = 0;
-	(void)rocprim::radix_sort_pairs<ReflSortConfig>(nullptr, r.sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (float4*)nullptr, (float4*)nullptr,
-	                                                r.n, 0, r.key_bits, 0, false);
-	r.total_floats = r.ntex * 4 + 2 * r.n + 8 * r.n + 2 * (r.nbands + 1) + (r.sort_bytes + 3) / 4 + 128;   // + slack to align the sort temp
+	(void)refl_sort(nullptr, r.sort_bytes, r.key_bits, nullptr, nullptr, nullptr, r.n, 0);
+	r.total_floats = r.ntex * 4 + 8 * r.n + 3 * r.n + (r.sort_bytes + 3) / 4 + 128;   // + slack to align the sort temp
 	return r;
 }
 extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, int height, int binned) {
@@ -782,36 +805,31 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 	const ReflScratch rs = refl_scratch(L, width, height);
 	const size_t ntex = rs.ntex;
 	if (scratch_floats < ntex * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than 6*L*L*4 floats"); return GSR_E_INVALID; }
-	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 31);
+	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 31) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
 	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, ntex * 4 * sizeof(float), stream));
 	StageTimer st_(GSR_STAGE_REFL_BWD, stream);
 	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
 	if (!binned) {
 		// texel gradients by float atomics straight from the pixel kernel (memory-side, ~2.5 requests per pixel)
 		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
-		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail, nullptr,
-		                                                  nullptr, 0u);
+		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail);
 	} else {
-		// binned: the pixel kernel stores one 16-byte entry per (pixel, corner); ONE radix pass orders the entries by the
-		// cube-face band of their texel (2048 texels = 32 KB of LDS); each band is accumulated in LDS by REFL_SPLIT
-		// workgroups and added to the staging buffer with contiguous atomics.  Float atomics per launch drop from ~25 M
-		// scattered dwords to ~6 M contiguous ones.
-		uint32_t* keys_in = reinterpret_cast<uint32_t*>(scratch + ntex * 4);
+		// binned: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
+		// (texel id, pixel) makes equal texels adjacent; refl_run_combine_kernel gathers the records in that order, sums runs in
+		// registers and a workgroup's texel range in LDS.
+		ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + ntex * 4);   // 32-byte aligned as long as scratch is
+		uint32_t* keys_in = reinterpret_cast<uint32_t*>(fp + rs.n);
 		uint32_t* keys_out = keys_in + rs.n;
-		float4* ent_in = reinterpret_cast<float4*>(keys_out + rs.n);
-		float4* ent_out = ent_in + rs.n;
-		uint2* ranges = reinterpret_cast<uint2*>(ent_out + rs.n);
-		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(ranges + (rs.nbands + 1)) + 255) & ~(uintptr_t)255);
+		uint32_t* pix_out = keys_out + rs.n;
+		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
 		deferred_refl_bwd_entries_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
 		                                                                                (int)L, width, height, g_final, g_refl_color, g_normal_world,
-		                                                                                g_normal_view, g_base, g_strength, g_fail, ent_in, keys_in,
-		                                                                                (uint32_t)rs.nbands);
+		                                                                                g_normal_view, g_base, g_strength, g_fail, scratch, fp, keys_in,
+		                                                                                (uint32_t)ntex);
 		size_t sb = rs.sort_bytes;
-		GSR_HIP_CHECK(rocprim::radix_sort_pairs<ReflSortConfig>(sort_temp, sb, keys_in, keys_out, ent_in, ent_out, rs.n, 0u, (unsigned)rs.key_bits,
-		                                                        stream, false));
-		GSR_HIP_CHECK(hipMemsetAsync(ranges, 0, (rs.nbands + 1) * sizeof(uint2), stream));
-		refl_band_ranges_kernel<<<(unsigned)((rs.n + 255) / 256), 256, 0, stream>>>(rs.n, keys_out, ranges);
-		refl_band_accumulate_kernel<<<dim3(REFL_SPLIT, (unsigned)rs.nbands), 256, 0, stream>>>(ent_out, ranges, ntex, scratch);
+		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, stream));
+		const size_t per_wg = (size_t)256 * REFL_CHUNK;
+		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, stream>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 	}
 	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, (int)L);
 	GSR_LAUNCH_CHECK(0, stream);

@@ -45,3 +45,21 @@ for wdt in (4, 8, 16):
     distinct = (tt.sort(dim=2).values.diff(dim=2) != 0).sum(2) + 1
     print(f"distinct texels per {wdt} consecutive pixels: {distinct.float().mean().item():.2f}")
 print("|n| < 0.5 fraction:", (allmap[2:5].norm(dim=0) < 0.5).float().mean().item())
+# ---- statistics of the sorted-footprint accumulation (refl_run_combine_kernel)
+ts = t.flatten().sort().values
+n = ts.numel()
+for per_wg in (2048, 4096):
+    m = n // per_wg * per_wg
+    g = ts[:m].reshape(-1, per_wg)
+    span = g[:, -1] - g[:, 0]
+    print(f"records/WG {per_wg}: texel span median {span.median().item()}, mean {span.float().mean().item():.0f}, max {span.max().item()}, "
+          f"WGs with span > 4096-130: {(span > 4096 - 130).float().mean().item():.3f}")
+    over = (g - g[:, :1]) > (4096 - 130)
+    print(f"   records beyond the window: {over.float().mean().item():.4f}")
+for ch in (8, 16):
+    m = n // ch * ch
+    g = ts[:m].reshape(-1, ch)
+    fl = (g[:, 1:] != g[:, :-1]).sum(1) + 1
+    print(f"chunk {ch}: flushes per chunk {fl.float().mean().item():.2f} -> LDS adds per record {12 * fl.float().mean().item() / ch:.2f}")
+cnt = torch.bincount(t.flatten(), minlength=6 * L * L)
+print("records per texel: max", cnt.max().item(), " texels holding half of the records:", (cnt.sort(descending=True).values.cumsum(0) < n // 2).sum().item())

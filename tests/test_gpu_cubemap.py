@@ -173,3 +173,48 @@ def test_fused_matches_composed_hip_path():
     # float32 on both sides; a direction a few ulps apart may pick neighbouring texel weights: tolerance, not bit equality
     assert (torch.abs(f_h - f_c) > 1e-3).float().mean().item() <= 1e-3
     assert (torch.abs(n_h - rn.permute(2, 0, 1)) > 1e-5).float().mean().item() == 0.0
+
+
+@pytest.mark.parametrize("L,W,H", [(128, 320, 200), (256, 320, 200), (600, 160, 96), (256, 64, 64), (16, 333, 77)])
+def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
+    """The sorted-footprint backward against the float-atomics one across the sort configurations it selects by cubemap
+    size (9-bit digits at L=128, 10-bit at L=256, the 8-bit default otherwise), with records beyond the LDS window
+    (few pixels on a large cubemap) and with an odd pixel count."""
+    import gaussian_renderer
+    from gaussian_renderer import deferred_reflection
+    cam = S.look_at_camera(W, H, eye=(0.5, -0.25, -3.0))
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    g = torch.Generator().manual_seed(L + W)
+    nv = torch.randn(3, H, W, generator=g) * torch.rand(1, H, W, generator=g)
+    nv[:, : H // 3] = 0.0   # a smooth region (r = d): long runs of equal texels
+    base, strength = torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    tex = torch.randn(6, 3, L, L, generator=g) * 0.5
+    fail = torch.zeros(3)
+    wf, wc, wn = torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g)
+
+    class Env:
+        pass
+    # float64 reference chain on the CPU
+    leaf = lambda x: x.double().clone().requires_grad_(True)
+    nv_r, base_r, s_r, tex_r, fail_r = leaf(nv), leaf(base), leaf(strength), leaf(tex), leaf(fail)
+    f_r, c_r, n_r = _reference_chain(nv_r, base_r, s_r, tex_r, fail_r, cam, W, H)
+    ((f_r * wf.double()).sum() + (c_r * wc.double()).sum() + (n_r * wn.double()).sum()).backward()
+    grads = {}
+    for binned in (True, False):
+        monkeypatch.setattr(gaussian_renderer, "REFLECTION_BACKWARD_BINNED", binned)
+        cu = lambda x: x.float().cuda().clone().requires_grad_(True)
+        nv_h, base_h, s_h, tex_h, fail_h = cu(nv), cu(base), cu(strength), cu(tex), cu(fail)
+        env = Env()
+        env.params = {"Cubemap_texture": tex_h, "Cubemap_failv": fail_h}
+        f_h, c_h, n_h = deferred_reflection(nv_h, base_h, s_h, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+        ((f_h * wf.cuda()).sum() + (c_h * wc.cuda()).sum() + (n_h * wn.cuda()).sum()).backward()
+        grads[binned] = [x.grad.cpu().numpy() for x in (nv_h, base_h, s_h, tex_h)]
+        # the texel gradient of each path against float64 (pixels whose float32 direction falls into the neighbouring
+        # texel cell move their contribution by one texel: a handful of texels, bounded by the max-norm tolerance)
+        # (the bilinear weights are differences of texel coordinates ~L/2: their float32 resolution grows with L)
+        assert rel_maxnorm(grads[binned][3], tex_r.grad.numpy()) <= (1e-4 if L <= 256 else 3e-4)
+        assert rel_maxnorm(grads[binned][1], base_r.grad.numpy()) <= 1e-5
+    for a, b in zip(grads[True][:3], grads[False][:3]):
+        assert rel_maxnorm(a, b) <= 1e-4   # same formulas in two kernels; contraction order differs and 1/|n| amplifies it
+    # the two kernels contract the direction arithmetic differently: texel coordinates an ulp apart, times L
+    assert rel_maxnorm(grads[True][3], grads[False][3]) <= (1e-4 if L <= 256 else 3e-4)
