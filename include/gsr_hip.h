@@ -153,8 +153,8 @@ int gsr_deferred_reflection_forward(const float* normal_view, const float* base_
  *   g_fail accumulated into.  scratch: caller-provided device buffer of `scratch_floats` floats (contents ignored).
  *   With at least gsr_deferred_reflection_scratch_floats(L, W, H, 0) = 6*L*L*4 floats the texel gradients are added
  *   with float atomics from the pixel kernel; with gsr_deferred_reflection_scratch_floats(L, W, H, 1) floats
- *   (~84 bytes per pixel) the binned path runs instead: one 16-byte entry per (pixel, bilinear corner), one radix
- *   pass by cube-face band, per-band accumulation in LDS. */
+ *   (~44 bytes per pixel + the sort's temporary storage; 16-byte aligned) the sorted path runs instead: one footprint
+ *   record per pixel, a radix sort by texel id, runs of equal texels summed in registers and LDS. */
 size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, int height, int binned);
 int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength,
                                      const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
