@@ -77,7 +77,18 @@ uint32_t higher_msb(uint32_t n) {
 
 // rocPRIM switches radix_sort_pairs to a merge sort below 1 Mi items (~22 small launches, 165 us for 1e6 pairs on MI355X);
 // Onesweep (histogram + one launch per 8 key bits) is ~3x faster there, so the switch point is lowered to 64 Ki items.
+// (11-bit digits — three passes over the 31 depth bits instead of four; they fit LDS only with the `match` ranking —
+// were measured too: 0.43 ms against 0.27 ms for the whole two-level sort.)
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+// The depth sort of P keys is launch-latency-bound (a pass over 1 M pairs moves 16 MB): rocPRIM's tuned config for 4-byte
+// pairs (512 threads x 12 items, 163 workgroups at P = 1 M) leaves a third of the CUs idle and chains its decoupled
+// look-back through few, long blocks.  1024 x 4 measured best at P = 1 M (whole two-level sort, ms): tuned 0.274,
+// 256x8 0.270, 512x4 0.251, 1024x2 0.250, 1024x3 0.233, 1024x4 0.220, 1024x6 0.251, 1024x8 0.235.  The second-level
+// sort of R tile ids is fastest with the tuned config (1024x4 0.240, 1024x8 0.226, 512x8 0.258 against 0.220).
+using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 4>, rocprim::kernel_config<1024, 4>, 8,
+                                                                                       rocprim::block_radix_rank_algorithm::match>,
+                                                   65536>;
 
 // tiles_touched read through the depth order: element i of the sequence the second scan runs over
 struct TouchedInOrder {
@@ -90,7 +101,7 @@ size_t scan_temp_bytes(size_t P) {
 	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
-	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+	(void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
 	                                (uint32_t*)nullptr, P, 0, 31, 0, false);
 	return std::max(a, std::max(b, c));
 }
@@ -266,7 +277,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// tiles_touched taken in that order
 		StageTimer st_(GSR_STAGE_SORT, stream);
 		size_t tmp = geom.scan_temp_bytes;
-		GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+		GSR_HIP_CHECK(rocprim::radix_sort_pairs<DepthSortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 		                                        rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
 		tmp = geom.scan_temp_bytes;
 		auto touched = rocprim::make_transform_iterator((const uint32_t*)geom.order, TouchedInOrder{geom.tiles_touched});

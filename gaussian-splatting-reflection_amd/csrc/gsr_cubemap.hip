@@ -759,9 +759,11 @@ struct ReflScratch {
 	size_t ntex, n, sort_bytes, total_floats;
 	int key_bits;
 };
+// workgroup shape measured at n = 2 M pairs (whole backward, ms): 256x12 0.361, 512x12 0.320, 1024x4 0.313, 1024x6 0.306,
+// 1024x8 0.297, 1024x12 0.309, 1024x16 0.314
 template <unsigned Bits>
 using ReflSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, Bits,
+                                                  rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, Bits,
                                                                                       rocprim::block_radix_rank_algorithm::match>,
                                                   65536>;
 // 17-bit texel ids at L = 128, 19-bit at L = 256: two passes with 9- or 10-bit digits instead of three with 8
