@@ -561,10 +561,43 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 			grx += a; gry += bb; grz += cc;
 		}
 	}
+	// flag == 0 already implies the unclamped 2x2 block; the corner test keeps the record format honest regardless
+	const bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
+	{
+		// rim pixels (~2/L of all, about one per wave): the wave serves them one at a time.  The pixel's corner texels and
+		// weights travel through SGPRs and lanes 0..11 each add one (corner, channel) value, so a rim pixel costs one atomic
+		// instruction whose twelve dwords fall into four 16-byte slots — four memory-side requests instead of twelve
+		// single-lane ones (float atomics are priced per request: 44 us -> 15 us per launch at C3).
+		const int lane = threadIdx.x & 63;
+		const int k_of_lane = lane / 3, c_of_lane = lane - 3 * k_of_lane;
+		// bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
+		const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
+		const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
+		unsigned long long todo = __ballot(live && !fail && !interior);
+		while (todo) {
+			const int src = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			uint32_t tk[4];
+			float wk[4], gk[3];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int f = __builtin_amdgcn_readlane(s.f[k], src), y = __builtin_amdgcn_readlane(s.y[k], src), x = __builtin_amdgcn_readlane(s.x[k], src);
+				tk[k] = (uint32_t)(((size_t)f * L + y) * L + x);
+				wk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w4[k]), src));
+			}
+#pragma unroll
+			for (int c = 0; c < 3; c++) gk[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(graw[c]), src));
+			const int corners = __builtin_amdgcn_readlane((int)s.is_vertex, src) ? 3 : 4;
+			if (k_of_lane < corners) {
+				const uint32_t t = k_of_lane == 0 ? tk[0] : k_of_lane == 1 ? tk[1] : k_of_lane == 2 ? tk[2] : tk[3];
+				const float w = k_of_lane == 0 ? wk[0] : k_of_lane == 1 ? wk[1] : k_of_lane == 2 ? wk[2] : wk[3];
+				const float g = c_of_lane == 0 ? gk[0] : c_of_lane == 1 ? gk[1] : gk[2];
+				atomicAdd(g_scratch + ((size_t)t << 2) + c_of_lane, w * g);
+			}
+		}
+	}
 	if (!live) return;
 	{
-		// flag == 0 already implies the unclamped 2x2 block; the corner test keeps the record format honest regardless
-		const bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
 		const uint32_t t00 = (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
 		if (interior) {
 			float* f = reinterpret_cast<float*>(footprints + pix);
@@ -572,18 +605,6 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 			f[4] = s.ky;
 		}
 		keys[pix] = interior ? t00 : no_key;
-		if (!fail && !interior) {
-			// rim: bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
-			const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
-			const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				if (k == 3 && s.is_vertex) continue;
-				float* dst = g_scratch + ((((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]) << 2);
-#pragma unroll
-				for (int c = 0; c < 3; c++) atomicAdd(dst + c, w4[k] * graw[c]);
-			}
-		}
 	}
 	g_strength[p] = gs;
 	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
