@@ -168,8 +168,12 @@ BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total
 // Emission order inside a Gaussian: y outer / x inner, as the reference.
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
-                                                         uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x) {
+                                                         uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
+                                                         uint2* __restrict__ ranges, uint32_t tiles) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
+	// the tile ranges are cleared here (tile_ranges_kernel fills the non-empty ones after the sort): a dispatch of its own
+	// costs ~5 us whatever it does
+	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
 	if (i >= P) return;
 	const uint32_t idx = order[i];
 	if (tiles_touched[idx] == 0) return;
@@ -255,7 +259,7 @@ static int* pinned_word() {
 }
 
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom, const ImageState& img,
-                BinningState* out_binning, int debug, hipStream_t stream) {
+                BinningState* out_binning, int prefiltered, int debug, hipStream_t stream) {
 	int* host = pinned_word();
 	if (!host) { set_error("hipHostMalloc for the num_rendered readback failed"); return GSR_E_HIP; }
 	{
@@ -265,7 +269,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		                                      stream, false));
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
 		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-		GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+		host[1] = 0;
+		if (prefiltered) GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));   // the trap flag is only ever set then
 	}
 	// the host waits on THIS point only, not on the level-1 work enqueued behind it
 	static thread_local hipEvent_t readback_done = nullptr;
@@ -299,11 +304,11 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	BinningState b = carve_binning(buf, (size_t)R, sort_bytes, nullptr);
 	*out_binning = b;
 
-	GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));
+	if (R == 0) GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));   // otherwise emit_tiles_kernel clears them
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
-		                                                       b.vals_unsorted, (uint32_t)tiles_x); }
+		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only

@@ -623,7 +623,7 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 	for (int c = 0; c < 3; c++) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
 }
 
-// scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] +=
+// scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] (written, not accumulated)
 __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap, int L) {
 	const size_t n = (size_t)6 * L * L;
 	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -631,9 +631,9 @@ __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* 
 	const size_t LL = (size_t)L * L;
 	const size_t f = t / LL, r = t - f * LL;
 	const float4 g = scratch[t];
-	g_cubemap[(f * 3 + 0) * LL + r] += g.x;
-	g_cubemap[(f * 3 + 1) * LL + r] += g.y;
-	g_cubemap[(f * 3 + 2) * LL + r] += g.z;
+	g_cubemap[(f * 3 + 0) * LL + r] = g.x;
+	g_cubemap[(f * 3 + 1) * LL + r] = g.y;
+	g_cubemap[(f * 3 + 2) * LL + r] = g.z;
 }
 
 // ---- accumulation of the footprints (see gsr_deferred_reflection_backward).  (texel id, pixel) pairs arrive sorted by

@@ -688,7 +688,7 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	GeomState geom = carve_geom(gbuf, P, G_REC_F4, 6, G_ACC_F, scan_bytes, nullptr);
 	ImageState img = carve_image(ibuf, HW, ntiles, 1, 1, nullptr);
 
-	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
+	if (prefiltered) GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));   // the flag is only written and read then
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 { StageTimer st_(GSR_STAGE_PREPROCESS, stream); 	gauss_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
 	                                                             colors_precomp, normals, refl_strengths, cam, radii, geom, tiles_x, tiles_y,
@@ -696,7 +696,7 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	GSR_LAUNCH_CHECK(debug, stream);
 
 	BinningState bin;
-	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
+	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, prefiltered, debug, stream);
 	if (R < 0) return R;
 
 	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);

@@ -109,7 +109,7 @@ uint32_t higher_msb(uint32_t n);
 // inclusive scan of tiles_touched -> num_rendered (pinned 4-byte readback) -> binning buffer via alloc
 // -> key/value emission -> radix sort -> tile ranges.  Returns num_rendered or <0.
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom,
-                const ImageState& img, BinningState* out_binning, int debug, hipStream_t stream);
+                const ImageState& img, BinningState* out_binning, int prefiltered, int debug, hipStream_t stream);
 
 }  // namespace gsr
 

@@ -143,11 +143,12 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
                          const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
                          const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
                          const float* __restrict__ refl, const uint8_t* __restrict__ env_scope_mask, SurfelCam cam, int* __restrict__ radii,
-                         GeomState g, int gx, int gy, int prefiltered) {
+                         GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights) {
 #pragma clang fp contract(off)
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
 	radii[idx] = 0;
+	gaussian_weights[idx] = 0.f;   // the tile kernel merges per-wave maxima into it with atomicMax
 	g.tiles_touched[idx] = 0;
 	g.depths[idx] = __int_as_float(0x7f7fffff);   // culled: sorts behind every visible Gaussian in the depth pre-sort
 	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
@@ -923,16 +924,15 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	GeomState geom = carve_geom(gbuf, P, S_REC_F4, 0, S_ACC_F, scan_bytes, nullptr);
 	ImageState img = carve_image(ibuf, HW, ntiles, 3, 2, nullptr);
 
-	GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));
-	GSR_HIP_CHECK(hipMemsetAsync(gaussian_weights, 0, (size_t)P * sizeof(float), stream));
+	if (prefiltered) GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));   // the flag is only written and read then
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 { StageTimer st_(GSR_STAGE_PREPROCESS, stream); 	surfel_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
 	                                                              transMat_precomp, colors_precomp, refl_strengths, env_scope_mask, cam, radii, geom,
-	                                                              tiles_x, tiles_y, prefiltered); }
+	                                                              tiles_x, tiles_y, prefiltered, gaussian_weights); }
 	GSR_LAUNCH_CHECK(debug, stream);
 
 	BinningState bin;
-	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, debug, stream);
+	const int R = run_binning(alloc, alloc_user, P, tiles_x, tiles_y, geom, img, &bin, prefiltered, debug, stream);
 	if (R < 0) return R;
 
 { StageTimer st_(GSR_STAGE_RENDER_FWD, stream);

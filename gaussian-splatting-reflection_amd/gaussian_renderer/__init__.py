@@ -117,7 +117,7 @@ class _DeferredReflection(torch.autograd.Function):
         g_refl_color = None if g_refl_color is None else g_refl_color.float().contiguous()
         g_normal_world = None if g_normal_world is None else g_normal_world.float().contiguous()
         g_nv, g_base, g_s = torch.empty_like(nv), torch.empty_like(bc), torch.empty_like(rs)
-        g_cm, g_fail = torch.zeros_like(cm), torch.zeros_like(fv)
+        g_cm, g_fail = torch.empty_like(cm), torch.zeros_like(fv)   # the library writes every texel gradient; g_fail is accumulated
         n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=cm.device)
         with torch.cuda.device(nv.device):
