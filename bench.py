@@ -105,7 +105,7 @@ def main():
     import gsr_synth as S
     import _gsr
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from gaussian_renderer import deferred_reflection
+    from gaussian_renderer import deferred_reflection, set_reflection_grad_sink
 
     if os.environ.get("GSR_DEV"):
         _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))   # development ablations only (tests/ablate.py)
@@ -139,9 +139,12 @@ def main():
     # the rasterizer's backward writes its parameter gradients straight into the flat all-reduce buffer
     sink = scene.grads.sink()
     rasterizer.set_grad_sink(sink)
+    rsink = scene.grads.sink(names=("cubemap", "fail"))   # and so does the reflection op's backward
+    set_reflection_grad_sink(rsink)
+    sunk = set(sink) | set(rsink)
 
     def step():
-        scene.grads.zero_except_(sink)     # cubemap + fail value are still accumulated by autograd
+        scene.grads.zero_except_(sunk)     # nothing left for autograd to accumulate: no fill at all
         means2D.grad = None
         final, allmap = forward()
         torch.autograd.backward([final, allmap], [g_final, g_allmap])
@@ -185,6 +188,7 @@ def main():
         from utils.loss_utils import photometric_loss
         tensors = {k: v.detach().clone() for k, v in scene.p.items()}
         rasterizer.set_grad_sink(None)
+        set_reflection_grad_sink(None)
         scene.release()
         # all learning rates 0: Adam does its full arithmetic and memory traffic but the scene stays the C3 configuration
         # (with real rates the random target image changes opacities/scales within a few steps and the render cost drifts)
@@ -192,12 +196,15 @@ def main():
         del tensors
         fsink = st.grads.sink()
         rasterizer.set_grad_sink(fsink)
+        frsink = st.grads.sink(names=("cubemap", "fail"))
+        set_reflection_grad_sink(frsink)
+        fsunk = set(fsink) | set(frsink)
         fenv = EnvMap(st.p["cubemap"], st.p["fail"])
         gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
 
         def full_step(it):
             st.update_learning_rate(it)
-            st.grads.zero_except_(fsink)
+            st.grads.zero_except_(fsunk)
             means2D.grad = None
             base, radii, allmap, refl_map, gw = rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
                                                            shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
@@ -223,6 +230,7 @@ def main():
         fdt = time.perf_counter() - t2
         fstages = _gsr.profile_collect()
         _gsr.profile_enable(False)
+        set_reflection_grad_sink(None)
         if dist_on:
             tmax = torch.tensor([fdt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

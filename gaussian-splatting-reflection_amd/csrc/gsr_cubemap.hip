@@ -624,9 +624,14 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 }
 
 // scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] (written, not accumulated)
-__global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap, int L) {
+__global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap,
+                                                                  float* __restrict__ g_fail, int L) {
 	const size_t n = (size_t)6 * L * L;
 	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t == 0) {   // the fail-value gradient was accumulated in the four floats behind the texel staging
+		const float4 gf = scratch[n];
+		g_fail[0] = gf.x; g_fail[1] = gf.y; g_fail[2] = gf.z;
+	}
 	if (t >= n) return;
 	const size_t LL = (size_t)L * L;
 	const size_t f = t / LL, r = t - f * LL;
@@ -774,7 +779,7 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
 	return 0;
 }
 
-// Scratch layout of the binned backward (floats): [texel staging ntex*4][footprints 8n][keys_in n][keys_out n][pixels_out n]
+// Scratch layout of the binned backward (floats): [texel staging ntex*4][fail-value gradient 4][pad 4][footprints 8n][keys_in n][keys_out n][pixels_out n]
 // [sort temp], n = H * W.
 struct ReflScratch {
 	size_t ntex, n, sort_bytes, total_floats;
@@ -804,12 +809,12 @@ static ReflScratch refl_scratch(uint32_t L, int width, int height) {
 	while (((size_t)1 << r.key_bits) <= r.ntex) r.key_bits++;   // keys take values 0..ntex (ntex = nothing to add)
 	r.sort_bytes = 0;
 	(void)refl_sort(nullptr, r.sort_bytes, r.key_bits, nullptr, nullptr, nullptr, r.n, 0);
-	r.total_floats = r.ntex * 4 + 8 * r.n + 3 * r.n + (r.sort_bytes + 3) / 4 + 128;   // + slack to align the sort temp
+	r.total_floats = (r.ntex + 2) * 4 + 8 * r.n + 3 * r.n + (r.sort_bytes + 3) / 4 + 128;   // + slack to align the sort temp
 	return r;
 }
 extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, int height, int binned) {
 	if (L == 0 || width <= 0 || height <= 0) return 0;
-	if (!binned) return (size_t)6 * L * L * 4;
+	if (!binned) return ((size_t)6 * L * L + 1) * 4;
 	return refl_scratch(L, width, height).total_floats;
 }
 
@@ -827,34 +832,35 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 	const size_t HW = (size_t)width * height;
 	const ReflScratch rs = refl_scratch(L, width, height);
 	const size_t ntex = rs.ntex;
-	if (scratch_floats < ntex * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than 6*L*L*4 floats"); return GSR_E_INVALID; }
+	if (scratch_floats < (ntex + 1) * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than (6*L*L+1)*4 floats"); return GSR_E_INVALID; }
+	float* fail_acc = scratch + ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
 	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 31) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
-	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, ntex * 4 * sizeof(float), stream));
+	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, (ntex + 1) * 4 * sizeof(float), stream));
 	StageTimer st_(GSR_STAGE_REFL_BWD, stream);
 	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
 	if (!binned) {
 		// texel gradients by float atomics straight from the pixel kernel (memory-side, ~2.5 requests per pixel)
 		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
-		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, g_fail);
+		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, fail_acc);
 	} else {
 		// binned: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
 		// (texel id, pixel) makes equal texels adjacent; refl_run_combine_kernel gathers the records in that order, sums runs in
 		// registers and a workgroup's texel range in LDS.
-		ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + ntex * 4);   // 32-byte aligned as long as scratch is
+		ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + (ntex + 1) * 4 + 4);   // 32-byte aligned as long as scratch is
 		uint32_t* keys_in = reinterpret_cast<uint32_t*>(fp + rs.n);
 		uint32_t* keys_out = keys_in + rs.n;
 		uint32_t* pix_out = keys_out + rs.n;
 		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
 		deferred_refl_bwd_entries_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
 		                                                                                (int)L, width, height, g_final, g_refl_color, g_normal_world,
-		                                                                                g_normal_view, g_base, g_strength, g_fail, scratch, fp, keys_in,
+		                                                                                g_normal_view, g_base, g_strength, fail_acc, scratch, fp, keys_in,
 		                                                                                (uint32_t)ntex);
 		size_t sb = rs.sort_bytes;
 		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, stream));
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, stream>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 	}
-	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, (int)L);
+	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }

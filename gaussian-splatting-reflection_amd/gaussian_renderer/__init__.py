@@ -117,14 +117,34 @@ class _DeferredReflection(torch.autograd.Function):
         g_refl_color = None if g_refl_color is None else g_refl_color.float().contiguous()
         g_normal_world = None if g_normal_world is None else g_normal_world.float().contiguous()
         g_nv, g_base, g_s = torch.empty_like(nv), torch.empty_like(bc), torch.empty_like(rs)
-        g_cm, g_fail = torch.empty_like(cm), torch.zeros_like(fv)   # the library writes every texel gradient; g_fail is accumulated
+        # the library writes every element of both gradients.  With a gradient sink (set_reflection_grad_sink) they go
+        # straight into caller-owned tensors and autograd gets None: no allocation, no `grad += new` pass
+        sink = reflection_grad_sink or {}
+        g_cm, g_fail = sink.get("cubemap"), sink.get("fail")
+        sunk_cm, sunk_fail = g_cm is not None, g_fail is not None
+        for t, like, name in ((g_cm, cm, "cubemap"), (g_fail, fv, "fail")):
+            if t is not None and (tuple(t.shape) != tuple(like.shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != like.device):
+                raise ValueError(f"reflection grad sink '{name}': expected contiguous float32 {tuple(like.shape)} on {like.device}")
+        g_cm = torch.empty_like(cm) if g_cm is None else g_cm
+        g_fail = torch.empty_like(fv) if g_fail is None else g_fail
         n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=cm.device)
         with torch.cuda.device(nv.device):
             check(lib.gsr_deferred_reflection_backward(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(g_final),
                                                        ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base), ptr(g_s), ptr(g_cm),
                                                        ptr(g_fail), ptr(scratch), n_scratch, stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
-        return g_nv, g_base, g_s, g_cm, g_fail, None
+        return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None
+
+
+# Optional gradient sink of the fused reflection op (not in the reference; the counterpart of GaussianRasterizer.set_grad_sink):
+# {"cubemap": float32 [6,3,L,L], "fail": float32 [3]} — e.g. views of gsr_dist.FlatGrads.  While set, the backward writes
+# THIS backward's cubemap / fail-value gradient into them (overwritten, not summed) and returns None to autograd.
+reflection_grad_sink = None
+
+
+def set_reflection_grad_sink(sink):
+    global reflection_grad_sink
+    reflection_grad_sink = dict(sink) if sink else None
 
 
 def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, world_view_transform, HWK, R, T):

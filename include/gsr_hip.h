@@ -149,9 +149,9 @@ int gsr_deferred_reflection_forward(const float* normal_view, const float* base_
                                     int width, int height, float* out_final, float* out_refl_color,
                                     float* out_normal_world, void* stream);
 /*   Upstream grads: g_final [3,H,W] (required), g_refl_color, g_normal_world may be NULL.
- *   Outputs: g_normal_view [3,H,W], g_base [3,H,W], g_strength [H,W], g_cubemap [6,3,L,L] fully written;
- *   g_fail [3] accumulated into.  scratch: caller-provided device buffer of `scratch_floats` floats (contents ignored).
- *   With at least gsr_deferred_reflection_scratch_floats(L, W, H, 0) = 6*L*L*4 floats the texel gradients are added
+ *   Outputs: g_normal_view [3,H,W], g_base [3,H,W], g_strength [H,W], g_cubemap [6,3,L,L], g_fail [3]: all fully
+ *   written.  scratch: caller-provided device buffer of `scratch_floats` floats (contents ignored).
+ *   With at least gsr_deferred_reflection_scratch_floats(L, W, H, 0) = (6*L*L+1)*4 floats the texel gradients are added
  *   with float atomics from the pixel kernel; with gsr_deferred_reflection_scratch_floats(L, W, H, 1) floats
  *   (~44 bytes per pixel + the sort's temporary storage; 16-byte aligned) the sorted path runs instead: one footprint
  *   record per pixel, a radix sort by texel id, runs of equal texels summed in registers and LDS. */

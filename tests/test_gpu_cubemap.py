@@ -218,3 +218,42 @@ def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
         assert rel_maxnorm(a, b) <= 1e-4   # same formulas in two kernels; contraction order differs and 1/|n| amplifies it
     # the two kernels contract the direction arithmetic differently: texel coordinates an ulp apart, times L
     assert rel_maxnorm(grads[True][3], grads[False][3]) <= (1e-4 if L <= 256 else 3e-4)
+
+
+def test_reflection_grad_sink_routes_cubemap_gradients():
+    """Extension: with a reflection gradient sink the cubemap / fail-value gradients land in the caller's tensors
+    (overwritten: the buffers start as NaN) and autograd leaves the leaves' .grad alone."""
+    import gaussian_renderer
+    from gaussian_renderer import deferred_reflection, set_reflection_grad_sink
+    W, H, L = 160, 96, 16
+    cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    g = torch.Generator().manual_seed(3)
+    nv = (torch.randn(3, H, W, generator=g) * torch.rand(1, H, W, generator=g)).cuda()
+    nv[:, :2, :2] = 0.0   # zero normals: r = d
+    base, strength = torch.rand(3, H, W, generator=g).cuda(), torch.rand(1, H, W, generator=g).cuda()
+    tex0, fail0 = S.make_cubemap(L, 3, 4)
+    wf = torch.randn(3, H, W, generator=g).cuda()
+
+    class Env:
+        pass
+
+    def run(sink):
+        tex = torch.from_numpy(tex0).cuda().requires_grad_(True)
+        fail = torch.from_numpy(fail0).cuda().requires_grad_(True)
+        env = Env()
+        env.params = {"Cubemap_texture": tex, "Cubemap_failv": fail}
+        set_reflection_grad_sink(sink)
+        try:
+            f, _, _ = deferred_reflection(nv, base, strength, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+            (f * wf).sum().backward()
+        finally:
+            set_reflection_grad_sink(None)
+        return tex, fail
+    tex_p, fail_p = run(None)
+    sink = {"cubemap": torch.full((6, 3, L, L), float("nan"), device="cuda"), "fail": torch.full((3,), float("nan"), device="cuda")}
+    tex_s, fail_s = run(sink)
+    assert tex_s.grad is None and fail_s.grad is None
+    assert torch.isfinite(sink["cubemap"]).all() and torch.isfinite(sink["fail"]).all()
+    assert rel_maxnorm(sink["cubemap"].cpu().numpy(), tex_p.grad.cpu().numpy()) <= 1e-5
+    np.testing.assert_allclose(sink["fail"].cpu().numpy(), fail_p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
