@@ -196,6 +196,10 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 #define G_WBATCH 64
 #define G_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
 template <bool INVDEPTH>
+// The vote tests the cull ellipse against the box of the wave's pixel CENTRES, and alpha >= 1/255 is exactly q <= q_max for
+// this variant (the screen-space blur is part of the conic), so the 5 % + 0.1 margin on q_max already makes the record
+// conservative; the pad only covers the float rounding of the edge minimisation.
+#define G_CULL_PAD 0.05f
 __global__ void __launch_bounds__(64)
 gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                              const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
@@ -231,7 +235,7 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		if (hit) {
 			id = point_list[range.x + (uint32_t)(base + lane)];
 			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - G_CULL_PAD, qx1 + G_CULL_PAD, qy0 - G_CULL_PAD, qy1 + G_CULL_PAD);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);
@@ -363,7 +367,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		if (hit) {
 			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
 			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - 0.5f, qx1 + 0.5f, qy0 - 0.5f, qy1 + 0.5f);
+				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - G_CULL_PAD, qx1 + G_CULL_PAD, qy0 - G_CULL_PAD, qy1 + G_CULL_PAD);
 			}
 		}
 		const unsigned long long mm = __ballot(hit);

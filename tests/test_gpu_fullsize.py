@@ -109,3 +109,23 @@ def test_full_size_gauss_variant_against_oracle():
     gh = hip.backward(g["dL_dcolor"], g["dL_dinvdepth"], g["dL_dnormal"], g["dL_drefl"])
     for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dnormals", "dL_drefl_strengths"):
         assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
+
+
+def test_full_size_gauss_variant_cull_bit_identity():
+    """Variant G with and without the per-wave footprint vote: the vote may only drop (wave, Gaussian) pairs in which no
+    pixel reaches alpha >= 1/255, so every output and the contributor counts must be bit-identical."""
+    import _gsr
+    from helpers import HipGauss
+    kw, cam, sc = scene_kwargs("G", P, W, H, 1003, -4.75, 3, (0, 0, 0))
+    outs, ncs = [], []
+    try:
+        for cull in (1, 0):
+            _gsr.set_option("cull", cull)
+            hip = HipGauss(kw, antialiasing=True)
+            outs.append(hip.out())
+            ncs.append(hip.state("n_contrib"))
+    finally:
+        _gsr.set_option("cull", 1)
+    assert np.array_equal(ncs[0], ncs[1])
+    for k in ("color", "normal_map", "invdepth", "refl_strength_map", "radii"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
