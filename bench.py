@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace-steps", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary end-to-end (loss + Adam) timing")
+    ap.add_argument("--serial-allreduce", action="store_true", help="N > 1: all-reduce inside every step instead of overlapping it with the next one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,19 +137,39 @@ def main():
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
 
-    # the rasterizer's backward writes its parameter gradients straight into the flat all-reduce buffer
-    sink = scene.grads.sink()
-    rasterizer.set_grad_sink(sink)
-    rsink = scene.grads.sink(names=("cubemap", "fail"))   # and so does the reflection op's backward
-    set_reflection_grad_sink(rsink)
-    sunk = set(sink) | set(rsink)
+    # the backward kernels write their parameter gradients straight into a flat all-reduce buffer (gradient sinks).  With
+    # more than one rank there are two such buffers used alternately: the all-reduce of step k (RCCL, its own stream) runs
+    # while step k+1 renders and writes the other buffer; a buffer is reused only after its all-reduce has completed.
+    # Nothing consumes the reduced gradients in this leg, so the pipelining changes no result; the end-to-end leg below
+    # (optimizer step after every all-reduce) has the strict dependency and reports the unhidden cost.
+    overlap = dist_on and not args.serial_allreduce
+    scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
+    bufs = [scene.grads] + ([scene.grads.twin()] if overlap else [])
+    sinks = [(b.sink(), b.sink(names=("cubemap", "fail"))) for b in bufs]
+    pending = [None] * len(bufs)
+    counter = [0]
 
     def step():
-        scene.grads.zero_except_(sunk)     # nothing left for autograd to accumulate: no fill at all
+        k = counter[0] % len(bufs)
+        counter[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()              # the current stream waits for this buffer's previous all-reduce
+            pending[k] = None
+        rasterizer.set_grad_sink(sinks[k][0])
+        set_reflection_grad_sink(sinks[k][1])   # every gradient is sunk: nothing left for autograd to zero or accumulate
         means2D.grad = None
         final, allmap = forward()
         torch.autograd.backward([final, allmap], [g_final, g_allmap])
-        scene.grads.all_reduce()
+        if overlap:
+            pending[k] = bufs[k].all_reduce_async()
+        else:
+            bufs[k].all_reduce()
+
+    def drain():
+        for k, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[k] = None
 
     def sync_all():
         if dist_on:
@@ -157,15 +178,38 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     sync_all()
     _gsr.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     sync_all()
     dt = time.perf_counter() - t0
     stages = _gsr.profile_collect()
     _gsr.profile_enable(False)
+
+    # N > 1, for transparency: the same steps with the all-reduce inside every step (what a strictly sequential loop pays)
+    serial_ms = None
+    if overlap:
+        def serial_step():
+            rasterizer.set_grad_sink(sinks[0][0])
+            set_reflection_grad_sink(sinks[0][1])
+            means2D.grad = None
+            final, allmap = forward()
+            torch.autograd.backward([final, allmap], [g_final, g_allmap])
+            bufs[0].all_reduce()
+        for _ in range(2):
+            serial_step()
+        sync_all()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            serial_step()
+        sync_all()
+        tser = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
+        dist.all_reduce(tser, op=dist.ReduceOp.MAX)
+        serial_ms = float(tser.item()) / args.steps * 1e3
 
     # forward-only render rate (render FPS @1080p), un-timed for the headline but reported
     with torch.no_grad():
@@ -265,7 +309,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C3: 1M Gaussians, 1920x1080, SH deg 3 + reflection/specular path (cubemap L=%d), fwd+bwd" % args.cubemap,
                        "gaussians": P, "width": W, "height": H, "num_rendered": R, "views_per_step_per_gpu": 1,
-                       "parallelism": "1 view per GPU + RCCL all-reduce of per-Gaussian grads" if dist_on else "single GPU"},
+                       "parallelism": ("1 view per GPU + RCCL all-reduce of per-Gaussian grads" + (", overlapped with the next step (double-buffered)" if overlap else ", inside every step")) if dist_on else "single GPU"},
             "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4),
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stages.items() if v[1] > 0},
             "step_algorithmic_GBps": round((fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
@@ -274,6 +318,10 @@ def main():
                          "traffic": pmc_traffic("surfel_render_bwd_wave_kernel", P, W, H),
                          "avg_launch_ms": round(bwd_ms / max(1, bwd_n), 4), "algorithmic_bytes_per_launch": bytes_bwd},
         }
+        if serial_ms is not None:
+            out["allreduce"] = {"payload_MB": round(scene_payload_mb, 1), "overlapped_ms_per_step": round(ms_per_step, 4),
+                                "serial_ms_per_step": round(serial_ms, 4),
+                                "what": "ms_per_step / value use the overlapped loop; serial = all-reduce inside every step"}
         if full is not None:
             out["full_train_step"] = full
         if not args.no_cpu_baseline and world == 1:

@@ -53,6 +53,15 @@ class FlatGrads:
             p.grad = self.flat[a:b].view(p.shape)
         return self
 
+    def twin(self):
+        """A second gradient buffer with the same layout that does NOT take over the parameters' .grad views: the other
+        half of a double buffer for gradient sinks, so that the all-reduce of one step can run while the next step's
+        backward writes the other buffer."""
+        other = FlatGrads.__new__(FlatGrads)
+        other.params, other.names, other.slices = self.params, list(self.names), dict(self.slices)
+        other.flat = torch.zeros_like(self.flat)
+        return other
+
     def zero_(self):
         self.flat.zero_()
 
@@ -79,6 +88,14 @@ class FlatGrads:
             if average:
                 self.flat.div_(dist.get_world_size(group))
         return self.flat
+
+    def all_reduce_async(self, group=None):
+        """Start the sum of the per-rank gradients and return the work handle (None without a process group of more than
+        one rank).  `handle.wait()` makes the CURRENT STREAM wait for the result (no host block with RCCL); until then
+        nothing may write this buffer."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return None
 
 
 def reduce_densification_stats(grad_norm_sum, visible_count, max_radii, group=None):

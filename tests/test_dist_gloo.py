@@ -91,3 +91,52 @@ def test_two_rank_gradient_allreduce_matches_serial(tmp_path):
     np.testing.assert_array_equal(red["vis"].numpy(), vis)
     np.testing.assert_array_equal(red["rad"].numpy(), rad)
     assert np.abs(tot).max() > 0 and vis.max() == n_views
+
+
+def _pipeline_worker(rank, world, port, steps, n, out_dir):
+    """The double-buffered loop of bench.py at N > 1: step k writes buffer k % 2 and starts its all-reduce; a buffer is
+    rewritten only after its previous all-reduce has been waited for."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_dist import FlatGrads
+    params = {"a": torch.zeros(n, 3, requires_grad=True), "b": torch.zeros(7, requires_grad=True)}
+    bufs = [FlatGrads(params)]
+    bufs.append(bufs[0].twin())
+    assert params["a"].grad.data_ptr() == bufs[0].view("a").data_ptr()       # the twin did not take the .grad views over
+    assert bufs[1].flat.data_ptr() != bufs[0].flat.data_ptr() and bufs[1].slices == bufs[0].slices
+    pending, results = [None, None], []
+    for k in range(steps):
+        j = k % 2
+        if pending[j] is not None:
+            pending[j].wait()
+            results.append(bufs[j].flat.clone())        # the reduced gradient of step k - 2
+            pending[j] = None
+        sink = bufs[j].sink(names=("a", "b"))
+        sink["a"].copy_(torch.full((n, 3), float(rank + 1) * (k + 1)))       # what the backward kernels do: overwrite
+        sink["b"].copy_(torch.arange(7, dtype=torch.float32) * (rank + 1) + k)
+        pending[j] = bufs[j].all_reduce_async()
+        assert pending[j] is not None
+    for j in ((steps % 2), ((steps + 1) % 2)):          # oldest first
+        if pending[j] is not None:
+            pending[j].wait()
+            results.append(bufs[j].flat.clone())
+    if rank == 0:
+        torch.save(torch.stack(results), os.path.join(out_dir, "pipeline.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_double_buffered_allreduce(tmp_path):
+    steps, n, world = 5, 1000, 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_pipeline_worker, args=(world, port, steps, n, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "pipeline.pt"), weights_only=True)
+    assert got.shape[0] == steps
+    rsum = sum(r + 1 for r in range(world))
+    for k in range(steps):
+        a = got[k][: n * 3]
+        b = got[k][n * 3: n * 3 + 7]
+        assert torch.all(a == float(rsum * (k + 1)))
+        assert torch.equal(b, torch.arange(7, dtype=torch.float32) * rsum + world * k)
