@@ -491,7 +491,7 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 	if (chan) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
 }
 
-// The same backward for the binned path, one lane per pixel: nothing here needs the four lanes of the quad version (they
+// The same backward for the sorted-footprint path (`binned` in the C ABI), one lane per pixel: nothing here needs the four lanes of the quad version (they
 // exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  A pixel whose bilinear
 // footprint lies inside one cube face (all but the half-texel rim, ~2/L of the pixels) emits ONE record {g_r, g_g, g_b, kx,
 // ky} plus the sort key "texel id of the upper-left corner": the other corners are t+1, t+L, t+L+1 and the four weights
@@ -779,7 +779,7 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
 	return 0;
 }
 
-// Scratch layout of the binned backward (floats): [texel staging ntex*4][fail-value gradient 4][pad 4][footprints 8n][keys_in n][keys_out n][pixels_out n]
+// Scratch layout of the sorted-footprint backward (floats): [texel staging ntex*4][fail-value gradient 4][pad 4][footprints 8n][keys_in n][keys_out n][pixels_out n]
 // [sort temp], n = H * W.
 struct ReflScratch {
 	size_t ntex, n, sort_bytes, total_floats;
@@ -843,7 +843,7 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
 		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, fail_acc);
 	} else {
-		// binned: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
+		// sorted footprints: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
 		// (texel id, pixel) makes equal texels adjacent; refl_run_combine_kernel gathers the records in that order, sums runs in
 		// registers and a workgroup's texel range in LDS.
 		ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + (ntex + 1) * 4 + 4);   // 32-byte aligned as long as scratch is

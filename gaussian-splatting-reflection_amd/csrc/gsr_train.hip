@@ -15,8 +15,9 @@
 namespace gsr {
 
 #define SSIM_R 5
-#define SSIM_T 16
-#define SSIM_HALO (SSIM_T + 2 * SSIM_R)   // 26
+#define SSIM_T 32                          // output tile: 32 x 32 pixels per workgroup, four per thread
+#define SSIM_HALO (SSIM_T + 2 * SSIM_R)   // 42
+#define SSIM_B 4                           // outputs per work item along the filtered direction: 4 + 10 loads instead of 4 x 11
 
 struct SsimWindow { float g[2 * SSIM_R + 1]; };
 
@@ -47,6 +48,9 @@ __device__ __forceinline__ void ssim_load_tile(const float* __restrict__ a, cons
 
 // Forward: per-pixel SSIM (utils/loss_utils.py:75-92) and |x - y|, block-reduced into sums[0] (L1) and sums[1] (SSIM);
 // optionally the SSIM map and the three planes d ssim / d mu1, d ssim / d E[x^2], d ssim / d E[xy] for the backward.
+// Both separable passes are register-blocked: a work item produces SSIM_B neighbouring outputs from one sliding window of
+// SSIM_B + 10 LDS reads (the kernel is LDS-read bound: 29 reads per output pixel instead of 90), every output still
+// accumulating its eleven taps in the same order.
 __global__ void __launch_bounds__(256)
 ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimWindow win, float C1, float C2,
                    float* __restrict__ partials, float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dsigma1_sq,
@@ -58,50 +62,67 @@ ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img
 	const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
 	ssim_load_tile(img1 + plane, img2 + plane, H, W, x0, y0, ta, tb);
 	__syncthreads();
-	// horizontal pass: 26 rows x 16 columns x 5 moments
-	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_T; i += 256) {
-		const int ly = i / SSIM_T, lx = i - ly * SSIM_T;
-		float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+	// horizontal pass: 42 rows x (32 / 4) strips x 5 moments
+	for (int i = threadIdx.x; i < SSIM_HALO * (SSIM_T / SSIM_B); i += 256) {
+		const int ly = i % SSIM_HALO, lx = (i / SSIM_HALO) * SSIM_B;   // lanes run down the rows: row pitch 43 / 33 words is odd, no bank conflicts
+		float a[SSIM_B + 10], b[SSIM_B + 10];
 #pragma unroll
-		for (int k = 0; k < 11; k++) {
-			const float w = win.g[k], a = ta[ly][lx + k], b = tb[ly][lx + k];
-			s1 += w * a; s2 += w * b; s11 += w * (a * a); s22 += w * (b * b); s12 += w * (a * b);
+		for (int k = 0; k < SSIM_B + 10; k++) { a[k] = ta[ly][lx + k]; b[k] = tb[ly][lx + k]; }
+#pragma unroll
+		for (int c = 0; c < SSIM_B; c++) {
+			float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+			for (int k = 0; k < 11; k++) {
+				const float w = win.g[k], av = a[c + k], bv = b[c + k];
+				s1 += w * av; s2 += w * bv; s11 += w * (av * av); s22 += w * (bv * bv); s12 += w * (av * bv);
+			}
+			hs[0][ly][lx + c] = s1; hs[1][ly][lx + c] = s2; hs[2][ly][lx + c] = s11; hs[3][ly][lx + c] = s22; hs[4][ly][lx + c] = s12;
 		}
-		hs[0][ly][lx] = s1; hs[1][ly][lx] = s2; hs[2][ly][lx] = s11; hs[3][ly][lx] = s22; hs[4][ly][lx] = s12;
 	}
 	__syncthreads();
-	const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-	const int gx = x0 + tx, gy = y0 + ty;
-	float l1 = 0.f, sv = 0.f;
-	if (gx < W && gy < H) {
-		float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+	// vertical pass: thread (tx, tq) owns the four rows 4 tq .. 4 tq + 3 of column tx
+	const int tx = threadIdx.x & 31, tq = threadIdx.x >> 5;
+	const int gx = x0 + tx;
+	float col[5][SSIM_B + 10];
 #pragma unroll
-		for (int k = 0; k < 11; k++) {
-			const float w = win.g[k];
-			mu1 += w * hs[0][ty + k][tx]; mu2 += w * hs[1][ty + k][tx];
-			e11 += w * hs[2][ty + k][tx]; e22 += w * hs[3][ty + k][tx]; e12 += w * hs[4][ty + k][tx];
-		}
-		const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-		const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
-		const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
-		const float inv = 1.0f / (Cc * D);
-		sv = A * B * inv;
-		const size_t o = plane + (size_t)gy * W + gx;
-		l1 = fabsf(ta[ty + SSIM_R][tx + SSIM_R] - tb[ty + SSIM_R][tx + SSIM_R]);
-		if (ssim_map) ssim_map[o] = sv;
-		if (dm_dmu1) {
-			// with mu1, E[x^2], E[xy] as the independent conv outputs of image 1 (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
-			dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * sv * (D - Cc) * inv;
-			dm_dsigma1_sq[o] = -sv / D;
-			dm_dsigma12[o] = 2.f * A * inv;
+	for (int m = 0; m < 5; m++)
+#pragma unroll
+		for (int k = 0; k < SSIM_B + 10; k++) col[m][k] = hs[m][tq * SSIM_B + k][tx];
+	float l1 = 0.f, ssim_sum = 0.f;
+#pragma unroll
+	for (int r = 0; r < SSIM_B; r++) {
+		const int ty = tq * SSIM_B + r, gy = y0 + ty;
+		if (gx < W && gy < H) {
+			float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+#pragma unroll
+			for (int k = 0; k < 11; k++) {
+				const float w = win.g[k];
+				mu1 += w * col[0][r + k]; mu2 += w * col[1][r + k];
+				e11 += w * col[2][r + k]; e22 += w * col[3][r + k]; e12 += w * col[4][r + k];
+			}
+			const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+			const float sigma1_sq = e11 - mu1_sq, sigma2_sq = e22 - mu2_sq, sigma12 = e12 - mu12;
+			const float A = 2.f * mu12 + C1, B = 2.f * sigma12 + C2, Cc = mu1_sq + mu2_sq + C1, D = sigma1_sq + sigma2_sq + C2;
+			const float inv = 1.0f / (Cc * D);
+			const float sv = A * B * inv;
+			const size_t o = plane + (size_t)gy * W + gx;
+			l1 += fabsf(ta[ty + SSIM_R][tx + SSIM_R] - tb[ty + SSIM_R][tx + SSIM_R]);
+			ssim_sum += sv;
+			if (ssim_map) ssim_map[o] = sv;
+			if (dm_dmu1) {
+				// with mu1, E[x^2], E[xy] as the independent conv outputs of image 1 (sigma1^2 = E[x^2] - mu1^2, sigma12 = E[xy] - mu1 mu2)
+				dm_dmu1[o] = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * sv * (D - Cc) * inv;
+				dm_dsigma1_sq[o] = -sv / D;
+				dm_dsigma12[o] = 2.f * A * inv;
+			}
 		}
 	}
-	// block sums -> one partial pair per block (24 k blocks adding into ONE address serialise at the memory side: measured
-	// 0.32 ms for the 1080p loss with atomics); ssim_l1_reduce_kernel adds them up in a fixed order
-	float r[4] = {l1, sv, 0.f, 0.f};
-	wave_sum4(r);
+	// block sums -> one partial pair per block (thousands of blocks adding into ONE address serialise at the memory side:
+	// measured 0.32 ms for the 1080p loss with atomics); ssim_l1_reduce_kernel adds them up in a fixed order
+	float r4[4] = {l1, ssim_sum, 0.f, 0.f};
+	wave_sum4(r4);
 	const int wave = threadIdx.x >> 6;
-	if ((threadIdx.x & 63) == 63) { red[0][wave] = r[0]; red[1][wave] = r[1]; }
+	if ((threadIdx.x & 63) == 63) { red[0][wave] = r4[0]; red[1][wave] = r4[1]; }
 	__syncthreads();
 	if (threadIdx.x < 2) {
 		const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -143,31 +164,48 @@ ssim_l1_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img
 		t2[ly][lx] = in ? dm_dsigma12[o] : 0.f;
 	}
 	__syncthreads();
-	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_T; i += 256) {
-		const int ly = i / SSIM_T, lx = i - ly * SSIM_T;
-		float s0 = 0, s1 = 0, s2 = 0;
+	for (int i = threadIdx.x; i < SSIM_HALO * (SSIM_T / SSIM_B); i += 256) {
+		const int ly = i % SSIM_HALO, lx = (i / SSIM_HALO) * SSIM_B;   // lanes run down the rows: row pitch 43 / 33 words is odd, no bank conflicts
+		float v0[SSIM_B + 10], v1[SSIM_B + 10], v2[SSIM_B + 10];
+#pragma unroll
+		for (int k = 0; k < SSIM_B + 10; k++) { v0[k] = t0[ly][lx + k]; v1[k] = t1[ly][lx + k]; v2[k] = t2[ly][lx + k]; }
+#pragma unroll
+		for (int c = 0; c < SSIM_B; c++) {
+			float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+			for (int k = 0; k < 11; k++) {
+				const float w = win.g[k];
+				s0 += w * v0[c + k]; s1 += w * v1[c + k]; s2 += w * v2[c + k];
+			}
+			hs[0][ly][lx + c] = s0; hs[1][ly][lx + c] = s1; hs[2][ly][lx + c] = s2;
+		}
+	}
+	__syncthreads();
+	const int tx = threadIdx.x & 31, tq = threadIdx.x >> 5;
+	const int gx = x0 + tx;
+	if (gx >= W) return;
+	float col[3][SSIM_B + 10];
+#pragma unroll
+	for (int m = 0; m < 3; m++)
+#pragma unroll
+		for (int k = 0; k < SSIM_B + 10; k++) col[m][k] = hs[m][tq * SSIM_B + k][tx];
+	const float w_l1 = weights[0], w_ssim = weights[1];
+#pragma unroll
+	for (int r = 0; r < SSIM_B; r++) {
+		const int gy = y0 + tq * SSIM_B + r;
+		if (gy >= H) break;
+		float c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll
 		for (int k = 0; k < 11; k++) {
 			const float w = win.g[k];
-			s0 += w * t0[ly][lx + k]; s1 += w * t1[ly][lx + k]; s2 += w * t2[ly][lx + k];
+			c0 += w * col[0][r + k]; c1 += w * col[1][r + k]; c2 += w * col[2][r + k];
 		}
-		hs[0][ly][lx] = s0; hs[1][ly][lx] = s1; hs[2][ly][lx] = s2;
+		const size_t o = plane + (size_t)gy * W + gx;
+		const float x = img1[o], y = img2[o];
+		const float d = x - y;
+		const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // torch.abs backward: sign(), 0 at 0
+		dL_dimg1[o] = w_l1 * sgn + w_ssim * (c0 + 2.f * x * c1 + y * c2);
 	}
-	__syncthreads();
-	const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-	const int gx = x0 + tx, gy = y0 + ty;
-	if (gx >= W || gy >= H) return;
-	float c0 = 0, c1 = 0, c2 = 0;
-#pragma unroll
-	for (int k = 0; k < 11; k++) {
-		const float w = win.g[k];
-		c0 += w * hs[0][ty + k][tx]; c1 += w * hs[1][ty + k][tx]; c2 += w * hs[2][ty + k][tx];
-	}
-	const size_t o = plane + (size_t)gy * W + gx;
-	const float x = img1[o], y = img2[o];
-	const float d = x - y;
-	const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // torch.abs backward: sign(), 0 at 0
-	dL_dimg1[o] = weights[0] * sgn + weights[1] * (c0 + 2.f * x * c1 + y * c2);
 }
 
 // ---------------------------------------------------------------------------------------------------
