@@ -33,16 +33,31 @@ static SsimWindow make_window() {
 	return w;
 }
 
-// Stage the zero-padded halo tile of one plane pair into LDS.
-__device__ __forceinline__ void ssim_load_tile(const float* __restrict__ a, const float* __restrict__ b, int H, int W, int x0, int y0,
-                                               float (*ta)[SSIM_HALO + 1], float (*tb)[SSIM_HALO + 1]) {
-	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_HALO; i += 256) {
+// Stage the zero-padded halo tiles of up to three planes into LDS.  All of a thread's global loads are issued before the
+// first LDS store (the loop is fully unrolled into registers): with three workgroups per CU a load-store-load-store
+// sequence leaves the kernel waiting on seven dependent HBM round trips per tile.
+#define SSIM_LOADS ((SSIM_HALO * SSIM_HALO + 255) / 256)
+template <int NP>
+__device__ __forceinline__ void ssim_load_tiles(const float* const (&src)[NP], int H, int W, int x0, int y0, float (*const (&dst)[NP])[SSIM_HALO + 1]) {
+	float v[NP][SSIM_LOADS];
+#pragma unroll
+	for (int j = 0; j < SSIM_LOADS; j++) {
+		const int i = threadIdx.x + 256 * j;
 		const int ly = i / SSIM_HALO, lx = i - ly * SSIM_HALO;
 		const int gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
-		const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-		const size_t o = (size_t)gy * W + gx;
-		ta[ly][lx] = in ? a[o] : 0.f;
-		tb[ly][lx] = in ? b[o] : 0.f;
+		const bool in = i < SSIM_HALO * SSIM_HALO && gx >= 0 && gx < W && gy >= 0 && gy < H;
+		const size_t o = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+		for (int p = 0; p < NP; p++) v[p][j] = in ? src[p][o] : 0.f;
+	}
+#pragma unroll
+	for (int j = 0; j < SSIM_LOADS; j++) {
+		const int i = threadIdx.x + 256 * j;
+		const int ly = i / SSIM_HALO, lx = i - ly * SSIM_HALO;
+		if (i < SSIM_HALO * SSIM_HALO) {
+#pragma unroll
+			for (int p = 0; p < NP; p++) dst[p][ly][lx] = v[p][j];
+		}
 	}
 }
 
@@ -60,21 +75,28 @@ ssim_l1_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img
 	__shared__ float red[2][4];
 	const size_t plane = (size_t)blockIdx.z * H * W;
 	const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
-	ssim_load_tile(img1 + plane, img2 + plane, H, W, x0, y0, ta, tb);
+	{
+		const float* const src[2] = {img1 + plane, img2 + plane};
+		float (*const dst[2])[SSIM_HALO + 1] = {ta, tb};
+		ssim_load_tiles<2>(src, H, W, x0, y0, dst);
+	}
 	__syncthreads();
 	// horizontal pass: 42 rows x (32 / 4) strips x 5 moments
 	for (int i = threadIdx.x; i < SSIM_HALO * (SSIM_T / SSIM_B); i += 256) {
 		const int ly = i % SSIM_HALO, lx = (i / SSIM_HALO) * SSIM_B;   // lanes run down the rows: row pitch 43 / 33 words is odd, no bank conflicts
-		float a[SSIM_B + 10], b[SSIM_B + 10];
+		float a[SSIM_B + 10], b[SSIM_B + 10], aa[SSIM_B + 10], bb[SSIM_B + 10], ab[SSIM_B + 10];
 #pragma unroll
-		for (int k = 0; k < SSIM_B + 10; k++) { a[k] = ta[ly][lx + k]; b[k] = tb[ly][lx + k]; }
+		for (int k = 0; k < SSIM_B + 10; k++) {
+			a[k] = ta[ly][lx + k]; b[k] = tb[ly][lx + k];
+			aa[k] = a[k] * a[k]; bb[k] = b[k] * b[k]; ab[k] = a[k] * b[k];   // once per window element, not once per tap
+		}
 #pragma unroll
 		for (int c = 0; c < SSIM_B; c++) {
 			float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
 #pragma unroll
 			for (int k = 0; k < 11; k++) {
-				const float w = win.g[k], av = a[c + k], bv = b[c + k];
-				s1 += w * av; s2 += w * bv; s11 += w * (av * av); s22 += w * (bv * bv); s12 += w * (av * bv);
+				const float w = win.g[k];
+				s1 += w * a[c + k]; s2 += w * b[c + k]; s11 += w * aa[c + k]; s22 += w * bb[c + k]; s12 += w * ab[c + k];
 			}
 			hs[0][ly][lx + c] = s1; hs[1][ly][lx + c] = s2; hs[2][ly][lx + c] = s11; hs[3][ly][lx + c] = s22; hs[4][ly][lx + c] = s12;
 		}
@@ -154,14 +176,10 @@ ssim_l1_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img
 	__shared__ float hs[3][SSIM_HALO][SSIM_T + 1];
 	const size_t plane = (size_t)blockIdx.z * H * W;
 	const int x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
-	for (int i = threadIdx.x; i < SSIM_HALO * SSIM_HALO; i += 256) {
-		const int ly = i / SSIM_HALO, lx = i - ly * SSIM_HALO;
-		const int gx = x0 + lx - SSIM_R, gy = y0 + ly - SSIM_R;
-		const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-		const size_t o = plane + (size_t)gy * W + gx;
-		t0[ly][lx] = in ? dm_dmu1[o] : 0.f;
-		t1[ly][lx] = in ? dm_dsigma1_sq[o] : 0.f;
-		t2[ly][lx] = in ? dm_dsigma12[o] : 0.f;
+	{
+		const float* const src[3] = {dm_dmu1 + plane, dm_dsigma1_sq + plane, dm_dsigma12 + plane};
+		float (*const dst[3])[SSIM_HALO + 1] = {t0, t1, t2};
+		ssim_load_tiles<3>(src, H, W, x0, y0, dst);
 	}
 	__syncthreads();
 	for (int i = threadIdx.x; i < SSIM_HALO * (SSIM_T / SSIM_B); i += 256) {
