@@ -332,8 +332,13 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (pix >= HW) return;
 	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
+	// loads that do not depend on the reflected direction are issued together with the normal (one memory round trip less
+	// per wave; the kernel is a chain of dependent round trips at five waves per SIMD)
+	const float nvx = normal_view[pix], nvy = normal_view[HW + pix], nvz = normal_view[2 * HW + pix];
+	const float sv = strength[pix];
+	const float b0 = base[pix], b1 = base[HW + pix], b2 = base[2 * HW + pix];
 	ReflPixel o;
-	refl_pixel(cam, normal_view[pix], normal_view[HW + pix], normal_view[2 * HW + pix], px, py, o);
+	refl_pixel(cam, nvx, nvy, nvz, px, py, o);
 	float c[3];
 	if (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f) {
 		c[0] = fail_value[0]; c[1] = fail_value[1]; c[2] = fail_value[2];
@@ -352,12 +357,12 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 			c[ch] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
 		}
 	}
-	const float sv = strength[pix];
+	const float bs[3] = {b0, b1, b2};
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
 		const float rc = sigmoidf_(c[ch]);
 		out_refl[ch * HW + pix] = rc;
-		out_final[ch * HW + pix] = (1 - sv) * base[ch * HW + pix] + sv * rc;
+		out_final[ch * HW + pix] = (1 - sv) * bs[ch] + sv * rc;
 	}
 	out_nworld[pix] = o.nx;
 	out_nworld[HW + pix] = o.ny;
@@ -513,8 +518,19 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 	const bool live = pix < HW;
 	const size_t p = live ? pix : 0;
 	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
+	// every load that does not depend on the reflected direction is issued here, with the normal
+	const float nvx = normal_view[p], nvy = normal_view[HW + p], nvz = normal_view[2 * HW + p];
+	const float sv = strength[p];
+	float gfin[3], bas[3], grc[3] = {0.f, 0.f, 0.f}, gnw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		gfin[c] = g_final[c * HW + p];
+		bas[c] = base[c * HW + p];
+		if (g_refl_color) grc[c] = g_refl_color[c * HW + p];
+		if (g_nworld) gnw[c] = g_nworld[c * HW + p];
+	}
 	ReflPixel o;
-	refl_pixel(cam, normal_view[p], normal_view[HW + p], normal_view[2 * HW + p], px, py, o);
+	refl_pixel(cam, nvx, nvy, nvz, px, py, o);
 	const bool fail = (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f);
 	Seamless s;
 	int face = 0;
@@ -524,7 +540,6 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 		cube_uv(o.rx, o.ry, o.rz, u, v, face);
 		seamless_index(face, L, u, v, s);
 	}
-	const float sv = strength[p];
 	float graw[3] = {0.f, 0.f, 0.f};
 	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
 #pragma unroll
@@ -539,12 +554,12 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 			cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
 		}
 		const float rc = sigmoidf_(cval);
-		const float gf = g_final[c * HW + p];
-		const float b = base[c * HW + p];
+		const float gf = gfin[c];
+		const float b = bas[c];
 		if (live) g_base[c * HW + p] = (1 - sv) * gf;
 		gs += gf * (rc - b);
 		float gc = sv * gf;
-		if (g_refl_color) gc += g_refl_color[c * HW + p];
+		if (g_refl_color) gc += grc[c];
 		graw[c] = gc * rc * (1 - rc);   // sigmoid'
 		if (fail) {
 			if (live) atomicAdd(g_fail + c, graw[c]);
@@ -612,7 +627,7 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 	float gnx = -2.f * (o.dn * grx + grn * o.dx);
 	float gny = -2.f * (o.dn * gry + grn * o.dy);
 	float gnz = -2.f * (o.dn * grz + grn * o.dz);
-	if (g_nworld) { gnx += g_nworld[p]; gny += g_nworld[HW + p]; gnz += g_nworld[2 * HW + p]; }
+	if (g_nworld) { gnx += gnw[0]; gny += gnw[1]; gnz += gnw[2]; }
 	const float inv = 1.0f / (o.len + 1e-6f);
 	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
 	if (o.len > 0.f) {
