@@ -169,6 +169,7 @@ BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total
 // (A wave-cooperative version — the 64 Gaussians of a wave own one contiguous output run; lanes take instances begin + l,
 // + 64, ..., find the owner by bisection over the start offsets in LDS and store 256 contiguous bytes per instruction —
 // was measured slower: 75 us against 57 us at R = 3.9 M.)
+#define EMIT_BIG 32u   // a Gaussian with more instances than this is emitted by its whole wave
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
@@ -177,18 +178,44 @@ __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* 
 	// the tile ranges are cleared here (tile_ranges_kernel fills the non-empty ones after the sort): a dispatch of its own
 	// costs ~5 us whatever it does
 	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
-	if (i >= P) return;
-	const uint32_t idx = order[i];
-	if (tiles_touched[idx] == 0) return;
-	uint32_t off = (i == 0) ? 0u : offsets_sorted[i - 1];
-	const uint32_t r0 = rect[2 * idx], r1 = rect[2 * idx + 1];
+	// the instance count comes from the scan (two coalesced reads) and the rectangle is one 8-byte gather
+	const bool valid = i < P;
+	const uint32_t off = (valid && i > 0) ? offsets_sorted[i - 1] : 0u;
+	const uint32_t cnt = valid ? offsets_sorted[i] - off : 0u;
+	uint32_t idx = 0u, r0 = 0u, r1 = 0u;
+	if (cnt != 0u) {
+		idx = order[i];
+		const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
+		r0 = r.x; r1 = r.y;
+	}
 	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
-	for (uint32_t y = y0; y < y1; y++)
-		for (uint32_t x = x0; x < x1; x++) {
-			tile_keys[off] = y * tiles_x + x;
-			vals[off] = idx;
-			off++;
+	// small Gaussians (the mean is 4 instances): one thread writes its own short run
+	if (cnt != 0u && cnt <= EMIT_BIG) {
+		uint32_t o = off;
+		for (uint32_t y = y0; y < y1; y++)
+			for (uint32_t x = x0; x < x1; x++) {
+				tile_keys[o] = y * tiles_x + x;
+				vals[o] = idx;
+				o++;
+			}
+	}
+	// large ones (a near Gaussian covers up to every tile of the image; one thread looping over thousands of instances
+	// was the whole tail of this kernel) are emitted by all 64 lanes of the wave, 256 contiguous bytes per store
+	unsigned long long big = __ballot(cnt > EMIT_BIG);
+	const uint32_t lane = threadIdx.x & 63u;
+	while (big) {
+		const int src = __ffsll((long long)big) - 1;
+		big &= big - 1;
+		const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, src), b_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
+		const uint32_t b_idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
+		const uint32_t b_x0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, src), b_y0 = (uint32_t)__builtin_amdgcn_readlane((int)y0, src);
+		const uint32_t b_w = (uint32_t)__builtin_amdgcn_readlane((int)(x1 - x0), src);
+		for (uint32_t q = lane; q < b_cnt; q += 64u) {
+			const uint32_t dy = q / b_w, dx = q - dy * b_w;   // emission order inside a Gaussian: y outer / x inner
+			tile_keys[b_off + q] = (b_y0 + dy) * tiles_x + (b_x0 + dx);
+			vals[b_off + q] = b_idx;
 		}
+	}
 }
 
 // identifyTileRanges (DSR/DGR rasterizer_impl.cu:116-138)
