@@ -169,7 +169,7 @@ BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total
 // (A wave-cooperative version — the 64 Gaussians of a wave own one contiguous output run; lanes take instances begin + l,
 // + 64, ..., find the owner by bisection over the start offsets in LDS and store 256 contiguous bytes per instruction —
 // was measured slower: 75 us against 57 us at R = 3.9 M.)
-#define EMIT_BIG 32u   // a Gaussian with more instances than this is emitted by its whole wave
+#define EMIT_BIG 8u   // a Gaussian with more instances than this is emitted by its whole wave (C3: 32 -> 0.046 ms, 16 -> 0.045, 8 -> 0.042)
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
