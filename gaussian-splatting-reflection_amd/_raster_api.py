@@ -78,6 +78,10 @@ def build_api(v: Variant):
             ctx.raster_settings, ctx.num_rendered = settings, num_rendered
             ctx.save_for_backward(*[t[k] for k in v.saved], radii, *buffers)
             ctx.mark_non_differentiable(*[outputs[i] for i in v.nondiff_outputs])
+            # autograd would otherwise hand backward a zero-FILLED tensor for every output without a gradient, including the
+            # non-differentiable ones (radii, gaussian_weights: two P-sized fill dispatches per step that nobody reads)
+            ctx.set_materialize_grads(False)
+            ctx.out_meta = [(tuple(o.shape), o.dtype, o.device) for o in outputs]
             return outputs
 
         @staticmethod
@@ -86,6 +90,8 @@ def build_api(v: Variant):
             kept = ctx.saved_tensors
             saved = dict(zip(v.saved, kept[:len(v.saved)]))
             radii, buffers = kept[len(v.saved)], kept[len(v.saved) + 1:]
+            grad_outputs = [torch.zeros(m[0], dtype=m[1], device=m[2]) if (g is None and i not in v.nondiff_outputs) else g
+                            for i, (g, m) in enumerate(zip(grad_outputs, ctx.out_meta))]
             c_args = v.pack_backward(saved, settings, grad_outputs, ctx.num_rendered, buffers, radii)
             if v.snapshot_on_debug and settings.debug:
                 host_copy = cpu_deep_copy_tuple(c_args)

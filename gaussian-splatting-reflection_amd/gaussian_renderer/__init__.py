@@ -107,6 +107,7 @@ class _DeferredReflection(torch.autograd.Function):
                                                       ptr(refl_color), ptr(normal_world), stream_ptr(nv.device)),
                   "gsr_deferred_reflection_forward")
         ctx.save_for_backward(nv, bc, rs, cm, fv, cam)
+        ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None instead of zero-filled [3,H,W] tensors
         return final, refl_color, normal_world
 
     @staticmethod
@@ -190,6 +191,7 @@ class _SurfacePass(torch.autograd.Function):
                   "gsr_surface_forward")
         ctx.save_for_backward(am, raymat, sd)
         ctx.depth_ratio = float(depth_ratio)
+        ctx.set_materialize_grads(False)   # the backward takes NULL for an output without gradient
         return sd, sn
 
     @staticmethod
