@@ -17,7 +17,7 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libgsr_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 SOURCES = ["gsr_common.hip", "gsr_gauss.hip", "gsr_surfel.hip", "gsr_cubemap.hip", "gsr_train.hip", "gsr_surface.hip", "gsr_densify.hip"]
-HEADERS = ["gsr_internal.hpp", "gsr_math.hpp", os.path.join("..", "..", "include", "gsr_hip.h")]
+HEADERS = ["gsr_internal.hpp", "gsr_math.hpp", "gsr_sort.hpp", os.path.join("..", "..", "include", "gsr_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default; stated because parity of the integer outputs
 # (radii, tile rects, sort keys) relies on IEEE division and square root in the per-Gaussian kernels.

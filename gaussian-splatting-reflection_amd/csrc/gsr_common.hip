@@ -9,6 +9,7 @@
 #include <vector>
 #include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
+#include "gsr_sort.hpp"
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -80,15 +81,15 @@ uint32_t higher_msb(uint32_t n) {
 // (11-bit digits — three passes over the 31 depth bits instead of four; they fit LDS only with the `match` ranking —
 // were measured too: 0.43 ms against 0.27 ms for the whole two-level sort.)
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
-// The depth sort of P keys is launch-latency-bound (a pass over 1 M pairs moves 16 MB): rocPRIM's tuned config for 4-byte
-// pairs (512 threads x 12 items, 163 workgroups at P = 1 M) leaves a third of the CUs idle and chains its decoupled
-// look-back through few, long blocks.  1024 x 4 measured best at P = 1 M (whole two-level sort, ms): tuned 0.274,
-// 256x8 0.270, 512x4 0.251, 1024x2 0.250, 1024x3 0.233, 1024x4 0.220, 1024x6 0.251, 1024x8 0.235.  The second-level
-// sort of R tile ids is fastest with the tuned config (1024x4 0.240, 1024x8 0.226, 512x8 0.258 against 0.220).
-using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 4>, rocprim::kernel_config<1024, 4>, 8,
-                                                                                       rocprim::block_radix_rank_algorithm::match>,
-                                                   65536>;
+// Both sorts go through gsr_sort.hpp (rocPRIM's Onesweep device code, one clear per sort instead of three dispatches per
+// pass).  Workgroup shapes: the depth sort of P keys is launch-latency-bound (a pass over 1 M pairs moves 16 MB) and
+// rocPRIM's tuned shape for 4-byte pairs (1024 threads x 16 items: 61 workgroups at P = 1 M) leaves most CUs idle;
+// 1024 x 4 measured best (whole two-level sort at P = 1 M, ms: tuned 0.274, 256x8 0.270, 512x4 0.251, 1024x2 0.250,
+// 1024x3 0.233, 1024x4 0.220, 1024x6 0.251, 1024x8 0.235; it also wins at 0.3 M, 2 M and 5 M).  The second-level sort of
+// R tile ids keeps the tuned 1024 x 16 (1024x4 0.240, 1024x8 0.226, 512x8 0.258 against 0.220).
+#define DEPTH_SORT_SHAPE 1024, 4, 8
+#define TILE_SORT_SHAPE 1024, 16, 8
+static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
 
 // tiles_touched read through the depth order: element i of the sequence the second scan runs over
 struct TouchedInOrder {
@@ -101,14 +102,22 @@ size_t scan_temp_bytes(size_t P) {
 	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
-	(void)rocprim::radix_sort_pairs<DepthSortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-	                                (uint32_t*)nullptr, P, 0, 31, 0, false);
+	if (P <= SORT_MAX_ITEMS)
+		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+		                                            (uint32_t*)nullptr, P, 0u, 31u, 0);
+	else
+		(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+		                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
 	return std::max(a, std::max(b, c));
 }
 size_t sort_temp_bytes(size_t R, int end_bit) {
 	size_t bytes = 0;
-	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
-	                                end_bit, 0, false);
+	if (R <= SORT_MAX_ITEMS)
+		(void)onesweep_sort_pairs<TILE_SORT_SHAPE>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, R,
+		                                           0u, (unsigned)end_bit, 0);
+	else
+		(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
+		                                            end_bit, 0, false);
 	return bytes;
 }
 
@@ -312,8 +321,12 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// tiles_touched taken in that order
 		StageTimer st_(GSR_STAGE_SORT, stream);
 		size_t tmp = geom.scan_temp_bytes;
-		GSR_HIP_CHECK(rocprim::radix_sort_pairs<DepthSortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
-		                                        rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
+		if ((size_t)P <= SORT_MAX_ITEMS)
+			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream));
+		else
+			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
 		tmp = geom.scan_temp_bytes;
 		auto touched = rocprim::make_transform_iterator((const uint32_t*)geom.order, TouchedInOrder{geom.tiles_touched});
 		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, touched, geom.offsets_sorted, (size_t)P, rocprim::plus<uint32_t>(), stream,
@@ -342,8 +355,12 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
-		GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, sb, b.tile_keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R, 0u,
-		                                        (unsigned)bit, stream, false)); }
+		if ((size_t)R <= SORT_MAX_ITEMS)
+			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
+			                                                  (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream));
+		else
+			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, sb, b.tile_keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R,
+			                                                   0u, (unsigned)bit, stream, false)); }
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
 		{ StageTimer st_(GSR_STAGE_RANGES, stream);
 		tile_ranges_kernel<<<(R + 255) / 256, 256, 0, stream>>>(R, b.tile_keys, img.ranges); }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include "gsr_internal.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include "gsr_sort.hpp"
 #include <rocprim/iterator/counting_iterator.hpp>
 
 namespace gsr {
@@ -800,21 +801,14 @@ struct ReflScratch {
 	size_t ntex, n, sort_bytes, total_floats;
 	int key_bits;
 };
-// workgroup shape measured at n = 2 M pairs (whole backward, ms): 256x12 0.361, 512x12 0.320, 1024x4 0.313, 1024x6 0.306,
-// 1024x8 0.297, 1024x12 0.309, 1024x16 0.314
-template <unsigned Bits>
-using ReflSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, Bits,
-                                                                                      rocprim::block_radix_rank_algorithm::match>,
-                                                  65536>;
-// 17-bit texel ids at L = 128, 19-bit at L = 256: two passes with 9- or 10-bit digits instead of three with 8
+// Sort of (texel id, pixel) through gsr_sort.hpp (one clear per sort).  17-bit texel ids at L = 128, 19-bit at L = 256: two
+// passes with 9- or 10-bit digits instead of three with 8.  Workgroup shape measured at n = 2 M pairs (whole backward, ms):
+// 256x12 0.361, 512x12 0.320, 1024x4 0.313, 1024x6 0.306, 1024x8 0.297, 1024x12 0.309, 1024x16 0.314.
 static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
-	if (key_bits > 16 && key_bits <= 18)
-		return rocprim::radix_sort_pairs<ReflSortConfig<9>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
-	if (key_bits > 18 && key_bits <= 20)
-		return rocprim::radix_sort_pairs<ReflSortConfig<10>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
-	return rocprim::radix_sort_pairs<ReflSortConfig<8>>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+	if (key_bits > 16 && key_bits <= 18) return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+	if (key_bits > 18 && key_bits <= 20) return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 }
 static ReflScratch refl_scratch(uint32_t L, int width, int height) {
 	ReflScratch r;
@@ -849,7 +843,7 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 	const size_t ntex = rs.ntex;
 	if (scratch_floats < (ntex + 1) * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than (6*L*L+1)*4 floats"); return GSR_E_INVALID; }
 	float* fail_acc = scratch + ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
-	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 31) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
+	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 30) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
 	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, (ntex + 1) * 4 * sizeof(float), stream));
 	StageTimer st_(GSR_STAGE_REFL_BWD, stream);
 	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);

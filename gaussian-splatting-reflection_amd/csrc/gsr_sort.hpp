@@ -1,0 +1,100 @@
+// Onesweep radix sort of (uint32 key, 4-byte value) pairs with ONE clear per sort.
+//
+// rocPRIM's radix_sort_pairs issues, per digit pass, a memset of the decoupled look-back states and a memset of the ordered
+// block-id counter (gfx950 takes the atomic block-id path) in front of the pass kernel, plus one memset for the digit
+// histograms: 3 dispatches per pass.  A dispatch costs ~5 us on this part whatever it does, and the sorts of this library
+// are small enough (1-4 M pairs) to be bound by exactly that: the eight passes of a training step carried 17 fills.  This
+// driver gives every pass its own look-back states and block-id counter inside one temp region and clears the region once;
+// the device code is rocPRIM's own (rocprim::detail::onesweep_histograms / onesweep_scan_histograms / onesweep_iteration,
+// header-only, ROCm 7.2), instantiated with a fixed workgroup shape instead of the architecture dispatch.
+// Stable, ascending, keys compared on bits [begin_bit, end_bit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+namespace gsr {
+
+using SortOffset = unsigned int;
+using SortBlockId = rocprim::detail::block_id_wrapper<unsigned int, true>;
+using SortLookback = rocprim::detail::onesweep_lookback_state;
+
+template <unsigned BS, unsigned IPT, unsigned BITS>
+__global__ void __launch_bounds__(BS) sort_histogram_kernel(const uint32_t* keys, SortOffset* digit_counts, SortOffset size, SortOffset full_blocks,
+                                                             unsigned begin_bit, unsigned end_bit) {
+	rocprim::detail::onesweep_histograms<BS, IPT, BITS, false>(keys, digit_counts, size, full_blocks, rocprim::identity_decomposer{}, begin_bit, end_bit);
+}
+template <unsigned BS, unsigned BITS>
+__global__ void __launch_bounds__(BS) sort_scan_histograms_kernel(SortOffset* digit_offsets) {
+	rocprim::detail::onesweep_scan_histograms<BS, BITS>(digit_offsets);
+}
+template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
+__global__ void __launch_bounds__(BS) sort_pass_kernel(const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, unsigned size,
+                                                        SortOffset* digit_offsets_in, SortOffset* digit_offsets_out, SortLookback* lookback, unsigned bit,
+                                                        unsigned current_bits, unsigned full_blocks, SortBlockId block_id) {
+	rocprim::detail::onesweep_iteration<BS, IPT, BITS, false, rocprim::block_radix_rank_algorithm::match>(
+	    keys_in, keys_out, values_in, values_out, size, digit_offsets_in, digit_offsets_out, lookback, rocprim::identity_decomposer{}, bit, current_bits,
+	    full_blocks, block_id);
+}
+
+// temp == nullptr: returns the required bytes in `bytes` and does nothing else.  size < 2^30.
+template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
+hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, size_t size_,
+                               unsigned begin_bit, unsigned end_bit, hipStream_t stream) {
+	static_assert(sizeof(Value) == 4, "4-byte values");
+	constexpr unsigned radix = 1u << BITS, items_per_block = BS * IPT;
+	if (size_ >= ((size_t)1 << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
+	const unsigned size = (unsigned)size_;
+	const unsigned places = (end_bit - begin_bit + BITS - 1) / BITS;
+	const unsigned blocks = (size + items_per_block - 1) / items_per_block;
+	const unsigned full_blocks = size % items_per_block == 0 ? blocks : blocks - 1;
+	auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	// cleared region: [digit offsets radix*places][offsets of the next batch radix][per pass: look-back radix*blocks][block-id counters places]
+	const size_t o_digits = 0;
+	const size_t o_next = o_digits + up((size_t)radix * places * sizeof(SortOffset));
+	const size_t o_lookback = o_next + up((size_t)radix * sizeof(SortOffset));
+	const size_t lookback_pass = up((size_t)radix * (blocks ? blocks : 1) * sizeof(SortLookback));
+	const size_t o_ids = o_lookback + lookback_pass * places;
+	const size_t cleared = o_ids + up((size_t)places * 64);   // one counter per 64 bytes
+	const size_t o_keys_tmp = cleared;
+	const size_t o_vals_tmp = o_keys_tmp + up((size_t)size * 4);
+	const size_t total = o_vals_tmp + up((size_t)size * 4);
+	if (temp == nullptr) { bytes = total; return hipSuccess; }
+	if (bytes < total) return hipErrorInvalidValue;
+	if (size == 0) return hipSuccess;
+	char* base = static_cast<char*>(temp);
+	SortOffset* digits = reinterpret_cast<SortOffset*>(base + o_digits);
+	SortOffset* next = reinterpret_cast<SortOffset*>(base + o_next);
+	uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + o_keys_tmp);
+	Value* values_tmp = reinterpret_cast<Value*>(base + o_vals_tmp);
+
+	hipError_t e = hipMemsetAsync(base, 0, cleared, stream);
+	if (e != hipSuccess) return e;
+	sort_histogram_kernel<BS, IPT, BITS><<<blocks, BS, 0, stream>>>(keys_in, digits, size, full_blocks, begin_bit, end_bit);
+	sort_scan_histograms_kernel<BS, BITS><<<places, BS, 0, stream>>>(digits);
+
+	bool to_output = (places - 1) % 2 == 0, from_input = true;
+	unsigned place = 0;
+	for (unsigned bit = begin_bit; bit < end_bit; bit += BITS, ++place) {
+		const unsigned current_bits = (end_bit - bit) < BITS ? (end_bit - bit) : BITS;
+		SortLookback* lookback = reinterpret_cast<SortLookback*>(base + o_lookback + lookback_pass * place);
+		SortBlockId block_id = SortBlockId::create(base + o_ids + (size_t)place * 64);
+		SortOffset* d_in = digits + (size_t)place * radix;
+		uint32_t* k_out = to_output ? keys_out : keys_tmp;
+		Value* v_out = to_output ? values_out : values_tmp;
+		if (from_input) {
+			sort_pass_kernel<BS, IPT, BITS, ValuesIn, Value><<<blocks, BS, 0, stream>>>(keys_in, k_out, values_in, v_out, size, d_in, next, lookback, bit,
+			                                                                            current_bits, full_blocks, block_id);
+		} else {
+			const uint32_t* k_in = to_output ? keys_tmp : keys_out;
+			const Value* v_in = to_output ? values_tmp : values_out;
+			sort_pass_kernel<BS, IPT, BITS, const Value*, Value><<<blocks, BS, 0, stream>>>(k_in, k_out, v_in, v_out, size, d_in, next, lookback, bit,
+			                                                                                current_bits, full_blocks, block_id);
+		}
+		from_input = false;
+		to_output = !to_output;
+	}
+	return hipGetLastError();
+}
+
+}  // namespace gsr
