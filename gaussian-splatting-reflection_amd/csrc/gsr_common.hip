@@ -87,8 +87,12 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 // 1024 x 4 measured best (whole two-level sort at P = 1 M, ms: tuned 0.274, 256x8 0.270, 512x4 0.251, 1024x2 0.250,
 // 1024x3 0.233, 1024x4 0.220, 1024x6 0.251, 1024x8 0.235; it also wins at 0.3 M, 2 M and 5 M).  The second-level sort of
 // R tile ids keeps the tuned 1024 x 16 (1024x4 0.240, 1024x8 0.226, 512x8 0.258 against 0.220).
+#ifndef DEPTH_SORT_SHAPE
 #define DEPTH_SORT_SHAPE 1024, 4, 8
+#endif
+#ifndef TILE_SORT_SHAPE
 #define TILE_SORT_SHAPE 1024, 16, 8
+#endif
 static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
 
 // tiles_touched read through the depth order: element i of the sequence the second scan runs over
