@@ -100,20 +100,26 @@ struct TouchedInOrder {
 	const uint32_t* tiles_touched;
 	__host__ __device__ uint32_t operator()(uint32_t idx) const { return tiles_touched[idx]; }
 };
-// bytes of the P-sized temp region: the larger of (scan, scan through the order, depth pre-sort)
-size_t scan_temp_bytes(size_t P) {
-	size_t a = 0, b = 0, c = 0;
+// bytes of the P-sized temp region: the two scans share the first part, the depth pre-sort has the second one to itself
+// (its look-back state is cleared by the preprocess kernel, before the first scan runs)
+static size_t scan_part_bytes(size_t P) {
+	size_t a = 0, b = 0;
 	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
+	return (std::max(a, b) + 255) & ~(size_t)255;
+}
+static size_t depth_sort_bytes(size_t P) {
+	size_t c = 0;
 	if (P <= SORT_MAX_ITEMS)
 		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
 		                                            (uint32_t*)nullptr, P, 0u, 31u, 0);
 	else
 		(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
 		                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
-	return std::max(a, std::max(b, c));
+	return c;
 }
+size_t scan_temp_bytes(size_t P) { return scan_part_bytes(P) + depth_sort_bytes(P); }
 size_t sort_temp_bytes(size_t R, int end_bit) {
 	size_t bytes = 0;
 	if (R <= SORT_MAX_ITEMS)
@@ -144,6 +150,9 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.offsets_sorted = c.take<uint32_t>(P);
 	g.scan_temp = c.take<char>(scan_bytes);
 	g.scan_temp_bytes = scan_bytes;
+	g.depth_sort_temp = g.scan_temp ? static_cast<char*>(g.scan_temp) + scan_part_bytes(P) : nullptr;
+	g.depth_sort_bytes = depth_sort_bytes(P);
+	g.depth_sort_clear = P <= SORT_MAX_ITEMS ? onesweep_cleared_bytes<DEPTH_SORT_SHAPE>(P, 0u, 31u) : 0;
 	if (total) *total = c.size();
 	return g;
 }
@@ -186,11 +195,12 @@ BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
-                                                         uint2* __restrict__ ranges, uint32_t tiles) {
+                                                         uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	// the tile ranges are cleared here (tile_ranges_kernel fills the non-empty ones after the sort): a dispatch of its own
-	// costs ~5 us whatever it does
+	// the tile ranges (tile_ranges_kernel fills the non-empty ones after the sort) and the look-back state of the tile-id
+	// sort that follows are cleared here: a dispatch of its own costs ~5 us whatever it does
 	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
+	sort_clear_region(sort_clear, sort_clear_bytes, (size_t)i, (size_t)gridDim.x * 256u);
 	// the instance count comes from the scan (two coalesced reads) and the rectangle is one 8-byte gather
 	const bool valid = i < P;
 	const uint32_t off = (valid && i > 0) ? offsets_sorted[i - 1] : 0u;
@@ -307,7 +317,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	if (!host) { set_error("hipHostMalloc for the num_rendered readback failed"); return GSR_E_HIP; }
 	{
 		StageTimer st_(GSR_STAGE_SCAN, stream);
-		size_t tmp = geom.scan_temp_bytes;
+		size_t tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));   // the scans' part
 		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, geom.tiles_touched, geom.point_offsets, (size_t)P, rocprim::plus<uint32_t>(),
 		                                      stream, false));
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
@@ -324,14 +334,14 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// Gaussians (31 key bits: depths are positive floats, their bit patterns order like the values) and the scan of
 		// tiles_touched taken in that order
 		StageTimer st_(GSR_STAGE_SORT, stream);
-		size_t tmp = geom.scan_temp_bytes;
-		if ((size_t)P <= SORT_MAX_ITEMS)
-			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
-			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream));
+		size_t tmp = geom.depth_sort_bytes;
+		if ((size_t)P <= SORT_MAX_ITEMS)   // look-back state already cleared by the preprocess kernel
+			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, true));
 		else
-			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.scan_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
+			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
-		tmp = geom.scan_temp_bytes;
+		tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));
 		auto touched = rocprim::make_transform_iterator((const uint32_t*)geom.order, TouchedInOrder{geom.tiles_touched});
 		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, touched, geom.offsets_sorted, (size_t)P, rocprim::plus<uint32_t>(), stream,
 		                                      false));
@@ -354,14 +364,16 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	if (R == 0) GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));   // otherwise emit_tiles_kernel clears them
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
+		const bool own_sort = (size_t)R <= SORT_MAX_ITEMS;
+		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
 		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
-		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles); }
+		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
 		if ((size_t)R <= SORT_MAX_ITEMS)
 			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
-			                                                  (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream));
+			                                                  (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
 		else
 			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, sb, b.tile_keys_unsorted, b.tile_keys, b.vals_unsorted, b.point_list, (size_t)R,
 			                                                   0u, (unsigned)bit, stream, false)); }

@@ -513,9 +513,11 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
                                  int W, int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color,
                                  const float* __restrict__ g_nworld, float* __restrict__ g_normal_view, float* __restrict__ g_base,
                                  float* __restrict__ g_strength, float* __restrict__ g_fail, float* __restrict__ g_scratch,
-                                 ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, uint32_t no_key) {
+                                 ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, uint32_t no_key, void* sort_clear,
+                                 size_t sort_clear_bytes) {
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	sort_clear_region(sort_clear, sort_clear_bytes, pix, (size_t)gridDim.x * 256u);   // look-back state of the sort that follows
 	const bool live = pix < HW;
 	const size_t p = live ? pix : 0;
 	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
@@ -804,11 +806,19 @@ struct ReflScratch {
 // Sort of (texel id, pixel) through gsr_sort.hpp (one clear per sort).  17-bit texel ids at L = 128, 19-bit at L = 256: two
 // passes with 9- or 10-bit digits instead of three with 8.  Workgroup shape measured at n = 2 M pairs (whole backward, ms):
 // 256x12 0.361, 512x12 0.320, 1024x4 0.313, 1024x6 0.306, 1024x8 0.297, 1024x12 0.309, 1024x16 0.314.
-static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream) {
+static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
+                            bool pre_cleared = false) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
-	if (key_bits > 16 && key_bits <= 18) return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
-	if (key_bits > 18 && key_bits <= 20) return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
-	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+	if (key_bits > 16 && key_bits <= 18)
+		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+	if (key_bits > 18 && key_bits <= 20)
+		return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+}
+static size_t refl_sort_cleared_bytes(int key_bits, size_t n) {
+	if (key_bits > 16 && key_bits <= 18) return onesweep_cleared_bytes<1024, 8, 9>(n, 0u, (unsigned)key_bits);
+	if (key_bits > 18 && key_bits <= 20) return onesweep_cleared_bytes<1024, 8, 10>(n, 0u, (unsigned)key_bits);
+	return onesweep_cleared_bytes<1024, 8, 8>(n, 0u, (unsigned)key_bits);
 }
 static ReflScratch refl_scratch(uint32_t L, int width, int height) {
 	ReflScratch r;
@@ -863,9 +873,9 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		deferred_refl_bwd_entries_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
 		                                                                                (int)L, width, height, g_final, g_refl_color, g_normal_world,
 		                                                                                g_normal_view, g_base, g_strength, fail_acc, scratch, fp, keys_in,
-		                                                                                (uint32_t)ntex);
+		                                                                                (uint32_t)ntex, sort_temp, refl_sort_cleared_bytes(rs.key_bits, rs.n));
 		size_t sb = rs.sort_bytes;
-		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, stream));
+		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, stream, true));
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, stream>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 	}

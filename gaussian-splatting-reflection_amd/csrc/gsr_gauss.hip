@@ -9,6 +9,7 @@
 // A 16x16 tile is one 256-thread workgroup = 4 waves, each wave owning an 8x8 pixel quadrant so that
 // wave-uniform skips ("no lane of this wave touches Gaussian j") fire as often as possible.
 #include "gsr_internal.hpp"
+#include "gsr_sort.hpp"
 #include "gsr_math.hpp"
 
 namespace gsr {
@@ -85,6 +86,8 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
                         int antialiasing) {
 #pragma clang fp contract(off)
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
+	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
 	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;

@@ -76,8 +76,10 @@ struct GeomState {
 	uint32_t* depth_sorted;  // P        depth bits in ascending order (output of the depth pre-sort; keys only)
 	uint32_t* order;         // P        Gaussian index at each position of the depth order (stable: ties by index)
 	uint32_t* offsets_sorted;// P        inclusive scan of tiles_touched taken in depth order
-	void* scan_temp;         // shared by the two scans and the P-sized sort
+	void* scan_temp;         // temp of the two scans (shared) followed by the temp of the P-sized depth sort
 	size_t scan_temp_bytes;
+	void* depth_sort_temp;   // = scan_temp + scan part; its first depth_sort_clear bytes are zeroed by the preprocess kernel
+	size_t depth_sort_bytes, depth_sort_clear;
 };
 struct ImageState {
 	uint2* ranges;       // tiles

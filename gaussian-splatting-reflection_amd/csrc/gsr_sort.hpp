@@ -37,10 +37,30 @@ __global__ void __launch_bounds__(BS) sort_pass_kernel(const uint32_t* keys_in, 
 	    full_blocks, block_id);
 }
 
+// Bytes at the start of the temp region that must be zero when the sort starts (multiple of 256).  A caller that has a
+// kernel running in front of the sort anyway can clear them there (sort_clear_region below) and pass pre_cleared = true:
+// one dispatch less.
+template <unsigned BS, unsigned IPT, unsigned BITS>
+size_t onesweep_cleared_bytes(size_t size_, unsigned begin_bit, unsigned end_bit) {
+	constexpr unsigned radix = 1u << BITS, items_per_block = BS * IPT;
+	if (size_ >= ((size_t)1 << 30) || end_bit <= begin_bit) return 0;
+	const unsigned size = (unsigned)size_;
+	const unsigned places = (end_bit - begin_bit + BITS - 1) / BITS;
+	const unsigned blocks = (size + items_per_block - 1) / items_per_block;
+	auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	return up((size_t)radix * places * sizeof(SortOffset)) + up((size_t)radix * sizeof(SortOffset)) +
+	       up((size_t)radix * (blocks ? blocks : 1) * sizeof(SortLookback)) * places + up((size_t)places * 64);
+}
+// grid-stride clear of `bytes` (multiple of 16) at `ptr` (16-byte aligned) by the calling kernel's threads
+__device__ __forceinline__ void sort_clear_region(void* ptr, size_t bytes, size_t thread, size_t threads) {
+	uint4* p = static_cast<uint4*>(ptr);
+	for (size_t i = thread; i < bytes / 16; i += threads) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // temp == nullptr: returns the required bytes in `bytes` and does nothing else.  size < 2^30.
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
 hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, size_t size_,
-                               unsigned begin_bit, unsigned end_bit, hipStream_t stream) {
+                               unsigned begin_bit, unsigned end_bit, hipStream_t stream, bool pre_cleared = false) {
 	static_assert(sizeof(Value) == 4, "4-byte values");
 	constexpr unsigned radix = 1u << BITS, items_per_block = BS * IPT;
 	if (size_ >= ((size_t)1 << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
@@ -68,8 +88,10 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 	uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(base + o_keys_tmp);
 	Value* values_tmp = reinterpret_cast<Value*>(base + o_vals_tmp);
 
-	hipError_t e = hipMemsetAsync(base, 0, cleared, stream);
-	if (e != hipSuccess) return e;
+	if (!pre_cleared) {
+		hipError_t e = hipMemsetAsync(base, 0, cleared, stream);
+		if (e != hipSuccess) return e;
+	}
 	sort_histogram_kernel<BS, IPT, BITS><<<blocks, BS, 0, stream>>>(keys_in, digits, size, full_blocks, begin_bit, end_bit);
 	sort_scan_histograms_kernel<BS, BITS><<<places, BS, 0, stream>>>(digits);
 

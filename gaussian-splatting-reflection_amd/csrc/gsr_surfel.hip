@@ -7,6 +7,7 @@
 //   f4[0] = (x, y, Tu.x, Tu.y)   f4[1] = (Tu.z, Tv.x, Tv.y, Tv.z)   f4[2] = (Tw.x, Tw.y, Tw.z, n.x)
 //   f4[3] = (n.y, n.z, opacity, r)   f4[4] = (g, b, refl, mask)
 #include "gsr_internal.hpp"
+#include "gsr_sort.hpp"
 #include "gsr_math.hpp"
 
 namespace gsr {
@@ -146,6 +147,8 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
                          GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights) {
 #pragma clang fp contract(off)
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
+	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
 	if (idx >= P) return;
 	radii[idx] = 0;
 	gaussian_weights[idx] = 0.f;   // the tile kernel merges per-wave maxima into it with atomicMax
