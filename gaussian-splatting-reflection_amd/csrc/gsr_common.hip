@@ -260,34 +260,57 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint32_t*
 // Longest-first dispatch order of the tiles in ONE single-workgroup kernel: a counting sort on the list length quantised
 // to 1024 buckets (list scheduling only needs an approximate order; a full rocPRIM sort of ~8 k keys costs 30 us in
 // launches).  Order inside a bucket is whatever the LDS atomics produce; any permutation is correct.
+#define TILE_ORDER_REGS 16   // list lengths a thread keeps in registers (covers 16 384 tiles; beyond that they are re-read)
 __global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
 	__shared__ uint32_t hist[1024];
+	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_max;
 	const int t = threadIdx.x;
 	hist[t] = 0;
 	if (t == 0) s_max = 0;
-	__syncthreads();
+	// one pass over the ranges: the lengths stay in registers for the three phases (the first version re-read them from
+	// global memory in each phase: three dependent memory round trips in a one-workgroup kernel)
+	uint32_t len[TILE_ORDER_REGS];
 	uint32_t m = 0;
-	for (int i = t; i < tiles; i += 1024) m = max(m, ranges[i].y - ranges[i].x);
+#pragma unroll
+	for (int j = 0; j < TILE_ORDER_REGS; j++) {
+		const int i = t + 1024 * j;
+		const uint2 r = i < tiles ? ranges[i] : make_uint2(0u, 0u);
+		len[j] = r.y - r.x;
+		m = max(m, len[j]);
+	}
+	for (int i = t + 1024 * TILE_ORDER_REGS; i < tiles; i += 1024) m = max(m, ranges[i].y - ranges[i].x);
+	__syncthreads();
 	atomicMax(&s_max, m);
 	__syncthreads();
 	int shift = 0;
 	while ((s_max >> shift) >= 1024u) shift++;
-	for (int i = t; i < tiles; i += 1024) atomicAdd(&hist[1023u - ((ranges[i].y - ranges[i].x) >> shift)], 1u);   // bucket 0 = longest
+#pragma unroll
+	for (int j = 0; j < TILE_ORDER_REGS; j++)
+		if (t + 1024 * j < tiles) atomicAdd(&hist[1023u - (len[j] >> shift)], 1u);   // bucket 0 = longest
+	for (int i = t + 1024 * TILE_ORDER_REGS; i < tiles; i += 1024) atomicAdd(&hist[1023u - ((ranges[i].y - ranges[i].x) >> shift)], 1u);
 	__syncthreads();
-	// exclusive scan of the 1024 buckets (Hillis-Steele in LDS)
+	// exclusive scan of the 1024 buckets: inside each wave with shuffles, across the 16 waves through LDS
 	const uint32_t mine = hist[t];
-	uint32_t v = mine;
-	for (int off = 1; off < 1024; off <<= 1) {
-		const uint32_t o = t >= off ? hist[t - off] : 0u;
-		__syncthreads();
-		v += o;
-		hist[t] = v;
-		__syncthreads();
+	uint32_t incl = mine;
+	const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t o = __shfl_up(incl, off, 64);
+		if (lane >= off) incl += o;
 	}
-	hist[t] = v - mine;
+	if (lane == 63) s_wave[wave] = incl;
 	__syncthreads();
-	for (int i = t; i < tiles; i += 1024) {
+	uint32_t base = 0;
+	for (int w = 0; w < wave; w++) base += s_wave[w];
+	hist[t] = base + incl - mine;
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < TILE_ORDER_REGS; j++) {
+		const int i = t + 1024 * j;
+		if (i < tiles) order[atomicAdd(&hist[1023u - (len[j] >> shift)], 1u)] = (uint32_t)i;
+	}
+	for (int i = t + 1024 * TILE_ORDER_REGS; i < tiles; i += 1024) {
 		const uint32_t b = 1023u - ((ranges[i].y - ranges[i].x) >> shift);
 		order[atomicAdd(&hist[b], 1u)] = (uint32_t)i;
 	}

@@ -222,3 +222,18 @@ def test_pixels_without_contributors_report_zero_median():
     assert (no_[0] == 0).mean() > 0.5
     np.testing.assert_array_equal(nh, no_)
     np.testing.assert_array_equal(hip.out()["color"][:, no_[0] == 0], ref["color"][:, no_[0] == 0])
+
+
+def test_more_tiles_than_the_dispatch_order_keeps_in_registers():
+    """17 600 tiles: tile_order_kernel keeps 16 list lengths per thread in registers (16 384 tiles) and re-reads the rest; every
+    tile must still be dispatched exactly once (a missing or duplicated tile shows in the image and the contributor counts)."""
+    orc = _orc()
+    W, H = 2816, 1600
+    kw, _, _ = scene_kwargs("S", 3000, W, H, 321, -2.6, 1, (0.1, 0.2, 0.3))
+    o = orc.SurfelOracle(np.float32)
+    ref = o.forward(**kw)
+    hip = HipSurfel(kw)
+    out = hip.out()
+    assert out["num_rendered"] == ref["num_rendered"]
+    np.testing.assert_array_equal(hip.state("n_contrib").astype(np.int64), o.state("n_contrib").astype(np.int64))
+    assert psnr(out["color"], ref["color"]) >= 50
