@@ -106,7 +106,7 @@ def main():
     import gsr_synth as S
     import _gsr
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    from gaussian_renderer import deferred_reflection, set_reflection_grad_sink
+    from gaussian_renderer import deferred_reflection
 
     if os.environ.get("GSR_DEV"):
         _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))   # development ablations only (tests/ablate.py)
@@ -126,13 +126,15 @@ def main():
     g_allmap = torch.from_numpy(g["dL_dplanes"]).to(dev)
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     info = {}
+    refl_sink = [None]    # gradient sink of the fused reflection op for the next forward (bound per call)
 
     def forward():
         base, radii, allmap, refl_map, gw = rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
                                                        shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
                                                        scales=scene.p["scales"], rotations=scene.p["rotations"],
                                                        env_scope_mask=scene.mask)
-        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], HWK, ct["R"], ct["T"])
+        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], HWK, ct["R"], ct["T"],
+                                                     grad_sink=refl_sink[0])
         if base.grad_fn is not None:
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
@@ -157,7 +159,7 @@ def main():
             pending[k].wait()              # the current stream waits for this buffer's previous all-reduce
             pending[k] = None
         rasterizer.set_grad_sink(sinks[k][0])
-        set_reflection_grad_sink(sinks[k][1])   # every gradient is sunk: nothing left for autograd to zero or accumulate
+        refl_sink[0] = sinks[k][1]              # every gradient is sunk: nothing left for autograd to zero or accumulate
         means2D.grad = None
         final, allmap = forward()
         torch.autograd.backward([final, allmap], [g_final, g_allmap])
@@ -201,7 +203,7 @@ def main():
     if overlap:
         def serial_step():
             rasterizer.set_grad_sink(sinks[0][0])
-            set_reflection_grad_sink(sinks[0][1])
+            refl_sink[0] = sinks[0][1]
             means2D.grad = None
             final, allmap = forward()
             torch.autograd.backward([final, allmap], [g_final, g_allmap])
@@ -218,6 +220,8 @@ def main():
         serial_ms = float(tser.item()) / args.steps * 1e3
 
     # forward-only render rate (render FPS @1080p), un-timed for the headline but reported
+    rasterizer.set_grad_sink(None)
+    refl_sink[0] = None
     with torch.no_grad():
         for _ in range(2):
             forward()
@@ -237,8 +241,6 @@ def main():
         from gsr_train import DEFAULT_LRS, GaussianTrainState
         from utils.loss_utils import photometric_loss
         tensors = {k: v.detach().clone() for k, v in scene.p.items()}
-        rasterizer.set_grad_sink(None)
-        set_reflection_grad_sink(None)
         scene.release()
         # all learning rates 0: Adam does its full arithmetic and memory traffic but the scene stays the C3 configuration
         # (with real rates the random target image changes opacities/scales within a few steps and the render cost drifts)
@@ -247,7 +249,6 @@ def main():
         fsink = st.grads.sink()
         rasterizer.set_grad_sink(fsink)
         frsink = st.grads.sink(names=("cubemap", "fail"))
-        set_reflection_grad_sink(frsink)
         fsunk = set(fsink) | set(frsink)
         fenv = EnvMap(st.p["cubemap"], st.p["fail"])
         gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
@@ -259,7 +260,7 @@ def main():
             base, radii, allmap, refl_map, gw = rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
                                                            shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
                                                            rotations=st.p["rotations"], env_scope_mask=scene.mask)
-            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, ct["viewmatrix"], HWK, ct["R"], ct["T"])
+            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, ct["viewmatrix"], HWK, ct["R"], ct["T"], grad_sink=frsink)
             loss = photometric_loss(final, gt_image, 0.2)
             loss.backward()
             st.grads.all_reduce()
@@ -280,7 +281,6 @@ def main():
         fdt = time.perf_counter() - t2
         fstages = _gsr.profile_collect()
         _gsr.profile_enable(False)
-        set_reflection_grad_sink(None)
         if dist_on:
             tmax = torch.tensor([fdt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")   # GSR_LIB: development A/B builds only
 
 c_void_p, c_int, c_float, c_size_t, c_uint32, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t,
                                                          ctypes.c_uint32, ctypes.c_char_p)
@@ -49,6 +49,8 @@ def _load():
     lib.gsr_surfel_backward.restype = c_int
     lib.gsr_surfel_backward.argtypes = [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float,
                                         P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]
+    lib.gsr_surfel_backward_accum.restype = c_int
+    lib.gsr_surfel_backward_accum.argtypes = lib.gsr_surfel_backward.argtypes[:-2] + [c_int, c_int, P]
     lib.gsr_gauss_forward.restype = c_int
     lib.gsr_gauss_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
                                       c_float, c_float, c_int, P, P, P, P, c_int, P, c_int, P]
@@ -69,6 +71,12 @@ def _load():
     lib.gsr_deferred_reflection_scratch_floats.restype = c_size_t
     lib.gsr_deferred_reflection_scratch_floats.argtypes = [c_uint32, c_int, c_int, c_int]
     lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]
+    lib.gsr_deferred_reflection_backward_accum.restype = c_int
+    lib.gsr_deferred_reflection_backward_accum.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, P]
+    lib.gsr_normal_world_forward.restype = c_int
+    lib.gsr_normal_world_forward.argtypes = [P, P, c_int, c_int, P, P]
+    lib.gsr_normal_world_backward.restype = c_int
+    lib.gsr_normal_world_backward.argtypes = [P, P, c_int, c_int, P, P, P]
     lib.gsr_ssim_l1_forward.restype = c_int
     lib.gsr_ssim_l1_scratch_floats.restype = c_size_t
     lib.gsr_ssim_l1_scratch_floats.argtypes = [c_int, c_int, c_int]
@@ -98,7 +106,8 @@ def _load():
 
 lib = _load()
 
-EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_gauss_forward", "gsr_gauss_backward",
+EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
+            "gsr_deferred_reflection_backward_accum", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
             "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]

@@ -30,6 +30,18 @@ def cpu_deep_copy_tuple(input_tuple):
     return tuple(x.cpu().clone() if isinstance(x, torch.Tensor) else x for x in input_tuple)
 
 
+class GradSink:
+    """Gradient sink of one forward/backward pair (extension, not in the reference): `tensors` maps a gradient name
+    (means3D, shs, opacities, scales, rotations, refl_strengths, ...) to a preallocated contiguous float32 tensor — e.g.
+    views of one flat all-reduce / optimizer buffer (gsr_dist.FlatGrads).  The per-Gaussian backward kernel writes
+    (accumulate=False) or adds (accumulate=True) those gradients straight into them and autograd receives None for the
+    corresponding inputs: no zero-fill, no `grad += new` pass.  Not a tensor, so autograd passes it through untouched."""
+
+    def __init__(self, tensors, accumulate=False):
+        self.tensors = dict(tensors)
+        self.accumulate = bool(accumulate)
+
+
 @dataclass
 class Variant:
     c_module: object                                   # the package's _C module (ctypes-backed)
@@ -46,7 +58,7 @@ class Variant:
     pack_backward: Callable                            # (saved dict, settings, grad_outputs, num_rendered, buffers, radii) -> _C args
     grads_of: Callable                                 # _C backward return tuple -> dict tensor name -> gradient
     optional_grads: Tuple[str, ...]                    # inputs whose gradient is None when they were passed as placeholders
-    sinkable: Dict[str, str] = field(default_factory=dict)   # apply() tensor name -> gradient-sink key (S only)
+    sinkable: Dict[str, str] = field(default_factory=dict)   # apply() tensor name -> gradient-sink key
     snapshot_on_debug: bool = False
 
 
@@ -56,13 +68,15 @@ def build_api(v: Variant):
 
     def split_args(args):
         args = list(args)
+        sink = args.pop() if len(args) == n_args + 1 else None      # trailing GradSink (extension) or absent
         settings = args.pop(v.settings_pos)
-        return dict(zip(v.tensors, args)), settings
+        return dict(zip(v.tensors, args)), settings, sink
 
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, *args):
-            t, settings = split_args(args)
+            t, settings, sink = split_args(args)
+            ctx.grad_sink, ctx.n_inputs = sink, len(args)
             c_args = v.pack_forward(t, settings)
             if v.snapshot_on_debug and settings.debug:
                 host_copy = cpu_deep_copy_tuple(c_args)          # taken before anything can corrupt the inputs
@@ -93,38 +107,54 @@ def build_api(v: Variant):
             grad_outputs = [torch.zeros(m[0], dtype=m[1], device=m[2]) if (g is None and i not in v.nondiff_outputs) else g
                             for i, (g, m) in enumerate(zip(grad_outputs, ctx.out_meta))]
             c_args = v.pack_backward(saved, settings, grad_outputs, ctx.num_rendered, buffers, radii)
+            sink_kw = {} if ctx.grad_sink is None else {"grad_sink": ctx.grad_sink.tensors, "accumulate": ctx.grad_sink.accumulate}
             if v.snapshot_on_debug and settings.debug:
                 host_copy = cpu_deep_copy_tuple(c_args)
                 try:
-                    ret = v.c_module.rasterize_gaussians_backward(*c_args)
+                    ret = v.c_module.rasterize_gaussians_backward(*c_args, **sink_kw)
                 except Exception as ex:
                     torch.save(host_copy, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                     raise ex
             else:
-                ret = v.c_module.rasterize_gaussians_backward(*c_args)
+                ret = v.c_module.rasterize_gaussians_backward(*c_args, **sink_kw)
             g = v.grads_of(ret)
-            sink = getattr(v.c_module, "grad_sink", None) or {}
+            sink = ctx.grad_sink.tensors if ctx.grad_sink is not None else {}
             out = []
             for name in v.tensors:
                 grad = g.get(name)
                 if name in v.sinkable and v.sinkable[name] in sink:
-                    grad = None            # already written into the caller's sink tensor (see _C.set_grad_sink)
+                    grad = None            # already written (or added) into the caller's sink tensor by the backward kernel
                 elif name in v.optional_grads and (saved.get(name) is None or saved[name].numel() == 0):
                     grad = None            # autograd wants None for inputs that were passed as empty placeholders
                 out.append(grad)
             out.insert(v.settings_pos, None)
+            out += [None] * (ctx.n_inputs - len(out))     # the trailing GradSink argument, when present
             return tuple(out)
 
-    def rasterize_gaussians(*args):
+    def rasterize_gaussians(*args, grad_sink=None):
         if len(args) != n_args:
             raise TypeError(f"rasterize_gaussians() takes {n_args} positional arguments but {len(args)} were given")
-        return _RasterizeGaussians.apply(*args)
+        if grad_sink is None:
+            return _RasterizeGaussians.apply(*args)
+        return _RasterizeGaussians.apply(*args, grad_sink)
 
     class GaussianRasterizer(nn.Module):
         def __init__(self, raster_settings):
             super().__init__()
             self.raster_settings = raster_settings
+            self._grad_sink = None
+
+        def set_grad_sink(self, sink, accumulate=False):
+            """Extension (not in the reference): route THIS rasterizer's parameter gradients into caller-owned tensors.
+            `sink`: dict gradient name -> preallocated contiguous float32 tensor (see GradSink), or None to restore plain
+            autograd.  The sink is bound to each forward call made while it is set (it travels through the autograd
+            context), so two rasterizers, or two backward passes in flight, never see each other's sinks.
+            accumulate=False: the backward kernel overwrites the sink with this backward's gradient; True: it adds to it
+            (several views per optimizer step: zero the buffer once, then every backward accumulates on the device)."""
+            if sink and not v.sinkable:
+                raise NotImplementedError("this rasterizer variant has no gradient sinks")
+            self._grad_sink = GradSink(sink, accumulate) if sink else None
 
         def markVisible(self, positions):
             """Boolean mask of the points in front of the camera's near plane (frustum test of the rasterizer)."""
@@ -145,7 +175,7 @@ def build_api(v: Variant):
                 t[name] = v.placeholder(name, means3D.device) if value is None and name in PLACEHOLDERS else value
             args = [t[name] for name in v.tensors]
             args.insert(v.settings_pos, self.raster_settings)
-            return rasterize_gaussians(*args)
+            return rasterize_gaussians(*args, grad_sink=self._grad_sink)
 
     PLACEHOLDERS = {"sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp", "env_scope_mask"}
     # give forward() the reference's explicit signature (keyword names and defaults are part of the API)

@@ -642,21 +642,23 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 }
 
 // scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] (written, not accumulated)
+template <bool ACC>
 __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* __restrict__ scratch, float* __restrict__ g_cubemap,
                                                                   float* __restrict__ g_fail, int L) {
 	const size_t n = (size_t)6 * L * L;
 	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (t == 0) {   // the fail-value gradient was accumulated in the four floats behind the texel staging
 		const float4 gf = scratch[n];
-		g_fail[0] = gf.x; g_fail[1] = gf.y; g_fail[2] = gf.z;
+		g_fail[0] = (ACC ? g_fail[0] : 0.f) + gf.x; g_fail[1] = (ACC ? g_fail[1] : 0.f) + gf.y; g_fail[2] = (ACC ? g_fail[2] : 0.f) + gf.z;
 	}
 	if (t >= n) return;
 	const size_t LL = (size_t)L * L;
 	const size_t f = t / LL, r = t - f * LL;
 	const float4 g = scratch[t];
-	g_cubemap[(f * 3 + 0) * LL + r] = g.x;
-	g_cubemap[(f * 3 + 1) * LL + r] = g.y;
-	g_cubemap[(f * 3 + 2) * LL + r] = g.z;
+	float* o = g_cubemap + f * 3 * LL + r;
+	o[0] = (ACC ? o[0] : 0.f) + g.x;
+	o[LL] = (ACC ? o[LL] : 0.f) + g.y;
+	o[2 * LL] = (ACC ? o[2 * LL] : 0.f) + g.z;
 }
 
 // ---- accumulation of the footprints (see gsr_deferred_reflection_backward).  (texel id, pixel) pairs arrive sorted by
@@ -837,11 +839,11 @@ extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, 
 	return refl_scratch(L, width, height).total_floats;
 }
 
-extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+extern "C" int gsr_deferred_reflection_backward_accum(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                 const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                 const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                 float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
-                                                float* scratch, size_t scratch_floats, void* stream_) {
+                                                float* scratch, size_t scratch_floats, int accumulate, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
 	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
@@ -879,7 +881,62 @@ extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const 
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, stream>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 	}
-	unpack_cubemap_grad_kernel<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
+	auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
+	unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
 	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+
+extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                                const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                                const float* g_final, const float* g_refl_color, const float* g_normal_world,
+                                                float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
+                                                float* scratch, size_t scratch_floats, void* stream_) {
+	return gsr_deferred_reflection_backward_accum(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
+	                                              g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, 0, stream_);
+}
+
+// ---- shading normal alone (the reference's initial stage renders without the reflection chain but still returns
+// rend_normal = normalize(allmap[2:5] rotated to world space), gaussian_renderer/__init__.py:148,178-179 of the reference).
+__global__ void __launch_bounds__(256) normal_world_fwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ cam, size_t HW,
+                                                               float* __restrict__ out) {
+	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (pix >= HW) return;
+	const float vx = normal_view[pix], vy = normal_view[HW + pix], vz = normal_view[2 * HW + pix];
+	const float wx = vx * cam[0] + vy * cam[1] + vz * cam[2], wy = vx * cam[3] + vy * cam[4] + vz * cam[5], wz = vx * cam[6] + vy * cam[7] + vz * cam[8];
+	const float inv = 1.0f / (sqrtf(wx * wx + wy * wy + wz * wz) + 1e-6f);
+	out[pix] = wx * inv; out[HW + pix] = wy * inv; out[2 * HW + pix] = wz * inv;
+}
+__global__ void __launch_bounds__(256) normal_world_bwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ cam, size_t HW,
+                                                               const float* __restrict__ g_out, float* __restrict__ g_normal_view) {
+	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (pix >= HW) return;
+	const float vx = normal_view[pix], vy = normal_view[HW + pix], vz = normal_view[2 * HW + pix];
+	const float wx = vx * cam[0] + vy * cam[1] + vz * cam[2], wy = vx * cam[3] + vy * cam[4] + vz * cam[5], wz = vx * cam[6] + vy * cam[7] + vz * cam[8];
+	const float len = sqrtf(wx * wx + wy * wy + wz * wz);
+	const float inv = 1.0f / (len + 1e-6f);
+	const float gx = g_out[pix], gy = g_out[HW + pix], gz = g_out[2 * HW + pix];
+	// n = w / (|w| + eps):  g_w = g / (len + eps) - w (w . g) / (len (len + eps)^2), zero subgradient at len = 0
+	float ax = gx * inv, ay = gy * inv, az = gz * inv;
+	if (len > 0.f) {
+		const float k = (wx * gx + wy * gy + wz * gz) * inv * inv / len;
+		ax -= wx * k; ay -= wy * k; az -= wz * k;
+	}
+#pragma unroll
+	for (int c = 0; c < 3; c++) g_normal_view[c * HW + pix] = ax * cam[c] + ay * cam[3 + c] + az * cam[6 + c];
+}
+extern "C" int gsr_normal_world_forward(const float* normal_view, const float* cam, int width, int height, float* out_normal_world, void* stream_) {
+	if (width <= 0 || height <= 0 || !normal_view || !cam || !out_normal_world) { set_error("gsr_normal_world_forward: invalid argument"); return GSR_E_INVALID; }
+	const size_t HW = (size_t)width * height;
+	normal_world_fwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, (hipStream_t)stream_>>>(normal_view, cam, HW, out_normal_world);
+	GSR_LAUNCH_CHECK(0, (hipStream_t)stream_);
+	return 0;
+}
+extern "C" int gsr_normal_world_backward(const float* normal_view, const float* cam, int width, int height, const float* g_normal_world,
+                                         float* g_normal_view, void* stream_) {
+	if (width <= 0 || height <= 0 || !normal_view || !cam || !g_normal_world || !g_normal_view) { set_error("gsr_normal_world_backward: invalid argument"); return GSR_E_INVALID; }
+	const size_t HW = (size_t)width * height;
+	normal_world_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, (hipStream_t)stream_>>>(normal_view, cam, HW, g_normal_world, g_normal_view);
+	GSR_LAUNCH_CHECK(0, (hipStream_t)stream_);
 	return 0;
 }

@@ -138,6 +138,7 @@ __device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
 // computeColorFromSH backward (DSR backward.cu:20-139 / DGR backward.cu:23-142).
 // Writes dL_dsh[idx, 0:M, :] completely (zeros above the active degree, which the reference gets from
 // its torch::zeros) and returns the view-direction gradient w.r.t. the mean.
+template <bool ACC = false>
 __device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& s, F3 dir_orig, uint8_t clamped_bits, F3 dL_dRGB,
                                           float* __restrict__ dL_dshs) {
 	const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
@@ -204,19 +205,24 @@ __device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& 
 					const float g = ch == 0 ? dL_dRGB.x : (ch == 1 ? dL_dRGB.y : dL_dRGB.z);
 					e[c] = w[k] * g;
 				}
-				o4[q] = make_float4(e[0], e[1], e[2], e[3]);
+				if (ACC) {
+					const float4 old = o4[q];
+					o4[q] = make_float4(old.x + e[0], old.y + e[1], old.z + e[2], old.w + e[3]);
+				} else {
+					o4[q] = make_float4(e[0], e[1], e[2], e[3]);
+				}
 			}
 		}
 	} else {
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			if (k < M) {
-				out[3 * k + 0] = w[k] * dL_dRGB.x;
-				out[3 * k + 1] = w[k] * dL_dRGB.y;
-				out[3 * k + 2] = w[k] * dL_dRGB.z;
+				out[3 * k + 0] = ACC ? out[3 * k + 0] + w[k] * dL_dRGB.x : w[k] * dL_dRGB.x;
+				out[3 * k + 1] = ACC ? out[3 * k + 1] + w[k] * dL_dRGB.y : w[k] * dL_dRGB.y;
+				out[3 * k + 2] = ACC ? out[3 * k + 2] + w[k] * dL_dRGB.z : w[k] * dL_dRGB.z;
 			}
 		}
-		for (int k = 16; k < M; k++) {
+		for (int k = 16; k < M && !ACC; k++) {
 			out[3 * k + 0] = 0.f;
 			out[3 * k + 1] = 0.f;
 			out[3 * k + 2] = 0.f;

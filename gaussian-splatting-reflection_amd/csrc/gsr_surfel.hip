@@ -309,8 +309,18 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // for the other three quadrants (the reference synchronises the 256 threads of a tile twice per batch).
 #define S_WBATCH 64
 #define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
+#ifndef S_SUB
 #define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
-__global__ void __launch_bounds__(64)
+#endif
+#ifndef GSR_BWD_WPE
+#define GSR_BWD_WPE 4
+#endif
+#ifdef GSR_FWD_WPE
+#define GSR_FWD_ATTR __attribute__((amdgpu_waves_per_eu(GSR_FWD_WPE, GSR_FWD_WPE)))
+#else
+#define GSR_FWD_ATTR
+#endif
+__global__ void __launch_bounds__(64) GSR_FWD_ATTR
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
@@ -719,7 +729,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 }
 
 // 75 VGPRs.  Measured at C3 (balanced XCD mapping) with amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE, GSR_BWD_WPE)))
 surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
                               const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -738,6 +748,10 @@ __device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, con
 
 // compute_transmat_aabb + preprocessCUDA backward (DSR backward.cu:473-660), one thread per surfel.
 // Writes every output element (zeros for culled surfels).
+// ACC: the parameter gradients (mean3D, sh, opacity, scale, rotation, refl strength) are ADDED to the output tensors instead
+// of written: several views accumulate into one gradient buffer on the device (gsr_surfel_backward_accum).
+template <bool ACC> __device__ __forceinline__ void put(float* p, float v) { *p = ACC ? *p + v : v; }
+template <bool ACC>
 __global__ void __launch_bounds__(256)
 surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
                              const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -755,9 +769,9 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 	float dT[9] = {a2.x, a2.y, a2.z, -a2.w, -a3.x, -a3.y, a3.z, a3.w, a4v.x};
 	const float gm2x = a4v.y, gm2y = a4v.z;
 	dL_dcolor[3 * idx] = gcol[0]; dL_dcolor[3 * idx + 1] = gcol[1]; dL_dcolor[3 * idx + 2] = gcol[2];
-	dL_drefl[idx] = a0.w;
+	put<ACC>(dL_drefl + idx, a0.w);
 	dL_dnormal[3 * idx] = gnrm[0]; dL_dnormal[3 * idx + 1] = gnrm[1]; dL_dnormal[3 * idx + 2] = gnrm[2];
-	dL_dopacity[idx] = a1.w;
+	put<ACC>(dL_dopacity + idx, a1.w);
 
 	float dmean[3] = {0.f, 0.f, 0.f}, dscale[2] = {0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
 	float out_m2x = gm2x, out_m2y = gm2y;
@@ -862,19 +876,25 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 			ShRow s;
 			load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 			const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
-			const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(gcol[0], gcol[1], gcol[2]), dL_dsh);
+			const F3 dm = sh_backward<ACC>(idx, D, M, s, dir, clamped[idx], f3(gcol[0], gcol[1], gcol[2]), dL_dsh);
 			dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
-		} else {
+		} else if (!ACC) {
 			float* out = dL_dsh + (size_t)idx * M * 3;
 			for (int q = 0; q < M * 3; q++) out[q] = 0.f;
 		}
 	}
 	dL_dmean2D[3 * idx] = out_m2x; dL_dmean2D[3 * idx + 1] = out_m2y; dL_dmean2D[3 * idx + 2] = 0.f;
-	dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
+	put<ACC>(dL_dmean3D + 3 * idx, dmean[0]); put<ACC>(dL_dmean3D + 3 * idx + 1, dmean[1]); put<ACC>(dL_dmean3D + 3 * idx + 2, dmean[2]);
 #pragma unroll
 	for (int i = 0; i < 9; i++) dL_dtransMat[9 * idx + i] = dTout[i];
-	dL_dscale[2 * idx] = dscale[0]; dL_dscale[2 * idx + 1] = dscale[1];
-	reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	put<ACC>(dL_dscale + 2 * idx, dscale[0]); put<ACC>(dL_dscale + 2 * idx + 1, dscale[1]);
+	float4* rq = reinterpret_cast<float4*>(dL_drot) + idx;
+	if (ACC) {
+		const float4 r0 = *rq;
+		*rq = make_float4(r0.x + drot[0], r0.y + drot[1], r0.z + drot[2], r0.w + drot[3]);
+	} else {
+		*rq = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	}
 }
 
 }  // namespace gsr
@@ -947,14 +967,14 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	return R;
 }
 
-extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                    const float* shs, const float* colors_precomp, const float* refl_strengths, const float* scales,
                                    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
                                    void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
                                    const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
                                    float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
-                                   float* dL_drot, int debug, void* stream_) {
+                                   float* dL_drot, int accumulate, int debug, void* stream_) {
 	(void)colors_precomp; (void)refl_strengths; (void)scale_modifier; (void)transMat_precomp;
 	hipStream_t stream = (hipStream_t)stream_;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_surfel_backward: invalid size"); return GSR_E_INVALID; }
@@ -983,9 +1003,24 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 	// scales == NULL selects the transMat_precomp path in the per-surfel backward (DSR backward.cu:639)
-{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream); 	surfel_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, scales, rotations, geom.rec, cam,
-	                                                                  geom.acc, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths,
-	                                                                  dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot); }
+{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream);
+	auto kern = accumulate ? surfel_preprocess_bwd_kernel<true> : surfel_preprocess_bwd_kernel<false>;
+	kern<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, scales, rotations, geom.rec, cam, geom.acc, dL_dmean2D, dL_dnormal,
+	                                          dL_dopacity, dL_dcolor, dL_drefl_strengths, dL_dmean3D, dL_dtransMat, dL_dsh, dL_dscale, dL_drot); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return 0;
+}
+
+extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* refl_strengths, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                                   void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                                   const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                                   float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                                   float* dL_drot, int debug, void* stream_) {
+	return gsr_surfel_backward_accum(P, D, M, R, background, width, height, means3D, shs, colors_precomp, refl_strengths, scales, scale_modifier, rotations,
+	                                 transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+	                                 dL_dpix, dL_dothers, dL_drefl_strength_map, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths, dL_dmean3D,
+	                                 dL_dtransMat, dL_dsh, dL_dscale, dL_drot, 0, debug, stream_);
 }

@@ -58,7 +58,9 @@ def rasterize_gaussians(background, means3D, colors, normals, refl_strengths, op
 def rasterize_gaussians_backward(background, means3D, radii, colors, normals, refl_strengths, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
                                  dL_dout_normal_map, dL_dout_refl_strength_map, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 antialiasing, debug):
+                                 antialiasing, debug, *, grad_sink=None, accumulate=False):
+    if grad_sink or accumulate:
+        raise NotImplementedError("gradient sinks are provided for the surfel rasterizer (the one the training path calls) only")
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0

@@ -15,6 +15,7 @@ import _gsr  # noqa: E402
 from _gsr import check, f32c, lib, ptr, require_cuda, stream_ptr  # noqa: E402
 
 NUM_CHANNELS = 3
+SINKABLE = frozenset(("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"))   # gradients a grad_sink may take
 
 
 def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations, scale_modifier,
@@ -58,22 +59,15 @@ def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_streng
     return rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer, out_refl, gaussian_weights
 
 
-# Optional gradient sink (not in the reference): dict name -> preallocated contiguous float32 tensor for any of
-# means3D (P,3), shs (P,M,3), opacities (P,1), scales (P,2), rotations (P,4), refl_strengths (P,1).  While set, the backward
-# kernels write those gradients directly into the given tensors (e.g. views of one flat all-reduce / optimizer buffer,
-# gsr_dist.FlatGrads) and the autograd Function returns None for the corresponding inputs, so autograd neither
-# allocates nor accumulates them: the sink holds THIS backward's gradient (overwritten, not summed).
-grad_sink = None
-
-
-def set_grad_sink(sink):
-    global grad_sink
-    grad_sink = dict(sink) if sink else None
-
-
 def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, dL_dout_refl_strength_map, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, grad_sink=None, accumulate=False):
+    """Same positional arguments and return tuple as the reference's `_C.rasterize_gaussians_backward`.  Keyword-only
+    extension: `grad_sink` maps any of means3D (P,3), shs (P,M,3), opacities (P,1), scales (P,2), rotations (P,4),
+    refl_strengths (P,1) to a preallocated contiguous float32 tensor (e.g. views of one flat all-reduce / optimizer buffer,
+    gsr_dist.FlatGrads); the per-Gaussian backward kernel then writes — or, with accumulate=True, ADDS — those gradients
+    straight into them and the corresponding entries of the return tuple are those same tensors.  The sink belongs to
+    this call: there is no module-level state."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors), ("scales", scales),
                     ("rotations", rotations), ("transMat_precomp", transMat_precomp), ("viewmatrix", viewmatrix),
                     ("projmatrix", projmatrix), ("sh", sh), ("campos", campos), ("binningBuffer", binningBuffer),
@@ -87,9 +81,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     # the library writes every element, so no zero-fill is needed (the reference uses torch::zeros)
     mk0 = torch.empty if P != 0 else torch.zeros
 
+    if grad_sink:
+        unknown = set(grad_sink) - SINKABLE
+        if unknown:
+            raise ValueError(f"grad sink: unknown gradient name(s) {sorted(unknown)}; expected a subset of {sorted(SINKABLE)}")
+    if accumulate and (not grad_sink or not set(grad_sink) >= (SINKABLE - ({"shs"} if M == 0 else set()))):
+        # the kernel has ONE accumulate switch for all six parameter gradients: fresh (uninitialised) tensors cannot be added to
+        raise ValueError("accumulate=True needs a sink for every parameter gradient: " + ", ".join(sorted(SINKABLE)))
+
     def mk(shape, sink_name=None, **kw):
-        # gradient sink (extension, see set_grad_sink): the kernel writes this output straight into a caller-owned tensor
-        t = grad_sink.get(sink_name) if (grad_sink is not None and sink_name is not None) else None
+        # gradient sink: the kernel writes this output straight into a caller-owned tensor
+        t = grad_sink.get(sink_name) if (grad_sink and sink_name is not None) else None
         if t is not None:
             if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
                 raise ValueError(f"grad sink '{sink_name}': expected contiguous float32 {tuple(shape)} on {dev}, got {tuple(t.shape)} {t.dtype}")
@@ -108,12 +110,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
                 f32c(dL_dout_refl_strength_map, "dL_dout_refl_strength_map"), radii.contiguous()]
         bg, m3, shc, col, refl, sca, rot, tmp, vm, pm, cp, gcol, goth, grefl, rad = keep
         with torch.cuda.device(dev):
-            check(lib.gsr_surfel_backward(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
+            check(lib.gsr_surfel_backward_accum(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
                                           float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm), ptr(cp), float(tan_fovx),
                                           float(tan_fovy), ptr(rad), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), ptr(gcol),
                                           ptr(goth), ptr(grefl), ptr(dL_dmeans2D), ptr(dL_dnormal), ptr(dL_dopacity), ptr(dL_dcolors),
                                           ptr(dL_drefl), ptr(dL_dmeans3D), ptr(dL_dtransMat), ptr(dL_dsh), ptr(dL_dscales),
-                                          ptr(dL_drotations), int(bool(debug)), stream_ptr(dev)), "gsr_surfel_backward")
+                                          ptr(dL_drotations), int(bool(accumulate)), int(bool(debug)), stream_ptr(dev)), "gsr_surfel_backward")
     return dL_dmeans2D, dL_dcolors, dL_drefl, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -62,11 +62,3 @@ _VARIANT = Variant(
 
 GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)
 
-
-def _set_grad_sink(sink):
-    """Extension (not in the reference): route this rasterizer's parameter gradients into preallocated tensors, see
-    _C.set_grad_sink.  Pass None to restore plain autograd behaviour."""
-    _C.set_grad_sink(sink)
-
-
-GaussianRasterizer.set_grad_sink = staticmethod(_set_grad_sink)

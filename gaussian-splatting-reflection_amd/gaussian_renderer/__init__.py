@@ -1,12 +1,15 @@
-"""Renderer glue above the rasterizer: the caller side of the hot path, mirroring
-gaussian_renderer/__init__.py of the reference (render(), render_fast(), get_refl_color(), reflection(),
-sample_cubemap_color()) with the same arguments and output dictionaries.
+"""Caller side of the hot path: `render()`, `render_fast()` and `render_env_map()` with the arguments and output
+dictionaries of the reference's gaussian_renderer/__init__.py (render :42-219, render_fast :221-325, render_env_map
+:37-40), built on this package's rasterizer and three fused per-pixel HIP passes:
 
-The deferred reflection chain of the reference (normal rotate + normalise, camera-ray generation, reflect,
-cubemap lookup, sigmoid, lerp: ~12 torch ops over [H,W,3], gaussian_renderer/__init__.py:22-35,148,178-179,
-197-199 and utils/general_utils.py:177-197) runs here as ONE fused HIP kernel per direction
-(`deferred_reflection`); the un-fused composition through CubemapEncoder stays available
-(`pipe.fused_reflection = False`) and both are parity-tested against each other.
+  deferred_reflection   shading normal -> camera ray -> reflect -> seamless cubemap lookup -> sigmoid -> lerp with the base
+                        colour by the blended reflection strength (the reference: ~12 torch ops over [H,W,3],
+                        :22-35,148,178-179,197-199 and utils/general_utils.py:177-197) as ONE kernel per direction
+  shading_normal        the shading normal alone, for the initial stage that renders without the reflection chain
+  surface_pass          depth select + pseudo-normal from depth (:151-176, utils/point_utils.py:9-37) as one kernel
+
+There is no torch re-implementation of these chains in the product: the independently written float64 chains they are
+checked against live under tests/ (tests/helpers_chain.py).
 """
 import math
 import os
@@ -18,82 +21,77 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gsr  # noqa: E402
 from _gsr import check, lib, ptr, stream_ptr  # noqa: E402
+from _raster_api import GradSink  # noqa: E402
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 
 
-def reflection(rayd, normal):
-    refl = rayd - 2 * normal * torch.sum(rayd * normal, dim=-1, keepdim=True)
-    return refl
+# ------------------------------------------------------------------------------------------- per-camera constants
+class _Block:
+    """A small device tensor derived from camera tensors, kept together with the tensors it was built from and their
+    version counters.  Holding the sources keeps their storage alive, so a later camera can never be handed the same
+    addresses and be mistaken for this one (the reference recomputes everything per call; this only saves the ~10 tiny
+    host-side ops per step)."""
+
+    def __init__(self, sources, extra, value):
+        self.sources, self.versions, self.extra, self.value = sources, [t._version for t in sources], extra, value
+
+    def matches(self, sources, extra):
+        return (len(sources) == len(self.sources) and all(a is b for a, b in zip(sources, self.sources)) and
+                all(t._version == v for t, v in zip(sources, self.versions)) and extra == self.extra)
 
 
-def sample_cubemap_color(rays_d, env_map):
-    H, W = rays_d.shape[:2]
-    outcolor = torch.sigmoid(env_map(rays_d.reshape(-1, 3)))
-    outcolor = outcolor.reshape(H, W, 3).permute(2, 0, 1)
-    return outcolor
+_blocks = {}          # kind -> most recent _Block (one camera at a time is the training pattern; anything else rebuilds)
 
 
-_pixel_camera = {}
-
-
-def sample_camera_rays(HWK, R, T):
-    """utils/general_utils.py:177-197 (R is stored transposed in 3DGS cameras)."""
-    H, W, K = HWK
-    R = R.T
-    key = (int(H), int(W), tuple(np.asarray(K, dtype=np.float32).reshape(-1).tolist()), str(R.device))
-    pc = _pixel_camera.get(key)
-    if pc is None:
-        K = np.asarray(K).astype(np.float32)
-        i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
-        xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
-        pc = torch.tensor(np.dot(xy1, np.linalg.inv(K).T)).to(R.device)
-        _pixel_camera.clear()
-        _pixel_camera[key] = pc
-    rays_o = (-R.T @ T.unsqueeze(-1)).flatten()
-    pixel_world = (pc - T[None, None]).reshape(-1, 3) @ R
-    rays_d = pixel_world - rays_o[None]
-    rays_d = rays_d / torch.norm(rays_d, dim=1, keepdim=True)
-    return rays_d.reshape(H, W, 3)
-
-
-def get_refl_color(envmap, HWK, R, T, normal_map):  # RT W2C
-    rays_d = sample_camera_rays(HWK, R, T)
-    rays_d = reflection(rays_d, normal_map)
-    return sample_cubemap_color(rays_d, envmap)
-
-
-_cam_cache = {}
+def _cached_block(kind, sources, extra, build):
+    hit = _blocks.get(kind)
+    if hit is not None and hit.matches(sources, extra):
+        return hit.value
+    value = build()
+    _blocks[kind] = _Block(list(sources), extra, value)
+    return value
 
 
 def _cam_block(world_view_transform, HWK, R, T):
-    """Packs the 33 camera floats gsr_deferred_reflection_* expects (see csrc/gsr_cubemap.hip).  Cached per camera
-    (keyed on the tensors' storage and version counters) so that a training loop does not rebuild it every step."""
-    key = (world_view_transform.data_ptr(), world_view_transform._version, R.data_ptr(), R._version, T.data_ptr(), T._version,
-           int(HWK[0]), int(HWK[1]), np.asarray(HWK[2], dtype=np.float32).tobytes())
-    hit = _cam_cache.get(key)
-    if hit is not None:
-        return hit
-    dev = world_view_transform.device
-    K = np.asarray(HWK[2]).astype(np.float32)
-    Kinv = torch.tensor(np.linalg.inv(K), dtype=torch.float32, device=dev)
-    Rw = R.T.contiguous().float()
-    Tf = T.float()
-    rays_o = (-Rw.T @ Tf.unsqueeze(-1)).flatten()
-    cam = torch.cat([world_view_transform[:3, :3].contiguous().float().reshape(-1), Kinv.reshape(-1), Rw.reshape(-1), Tf.reshape(-1),
-                     rays_o.reshape(-1)]).contiguous()
-    if len(_cam_cache) > 256:
-        _cam_cache.clear()
-    _cam_cache[key] = cam
-    return cam
+    """The 33 camera floats gsr_deferred_reflection_* / gsr_normal_world_* expect (layout in csrc/gsr_cubemap.hip):
+    world-view rotation, K^-1, world-to-camera rotation, translation, camera centre."""
+    Kb = np.asarray(HWK[2], dtype=np.float32)
+
+    def build():
+        dev = world_view_transform.device
+        Kinv = torch.tensor(np.linalg.inv(Kb), dtype=torch.float32, device=dev)
+        Rw = R.T.contiguous().float()
+        Tf = T.float()
+        centre = (-Rw.T @ Tf.unsqueeze(-1)).flatten()
+        return torch.cat([world_view_transform[:3, :3].contiguous().float().reshape(-1), Kinv.reshape(-1), Rw.reshape(-1), Tf.reshape(-1),
+                          centre.reshape(-1)]).contiguous()
+    return _cached_block("cam", (world_view_transform, R, T), (int(HWK[0]), int(HWK[1]), Kb.tobytes()), build)
 
 
-# True: sort-and-accumulate-in-LDS path of the reflection backward (needs ~84 bytes of scratch per pixel); False: float atomics
+def _ray_block(view):
+    """Device float[12] for gsr_surface_*: rays_d(x, y) = (x, y, 1) @ M with M = intrins^-1.T @ c2w[:3,:3].T (nine floats,
+    row-major) followed by the camera centre, where intrins is the 3x3 pixel projection the reference derives from
+    full_proj_transform and an (W/2, H/2)-centred NDC-to-pixel matrix (utils/point_utils.py:9-23)."""
+    wvt, fpt = view.world_view_transform, view.full_proj_transform
+    W, H = int(view.image_width), int(view.image_height)
+
+    def build():
+        c2w = (wvt.T).inverse()
+        ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=torch.float32, device=wvt.device).T
+        intrins = ((c2w.T @ fpt) @ ndc2pix)[:3, :3].T
+        M = intrins.inverse().T @ c2w[:3, :3].T
+        return torch.cat([M.reshape(-1), c2w[:3, 3].reshape(-1)]).float().contiguous()
+    return _cached_block("ray", (wvt, fpt), (W, H), build)
+
+
+# ------------------------------------------------------------------------------------------- fused pixel passes
+# True: sorted-footprint path of the reflection backward (~44 bytes of scratch per pixel); False: float atomics
 REFLECTION_BACKWARD_BINNED = True
 
 
 class _DeferredReflection(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, normal_view, base_color, refl_strength, cubemap, fail_value, cam):
+    def forward(ctx, normal_view, base_color, refl_strength, cubemap, fail_value, cam, sink):
         nv, bc, rs = normal_view.float().contiguous(), base_color.float().contiguous(), refl_strength.float().contiguous()
         cm, fv = cubemap.float().contiguous(), fail_value.float().contiguous()
         if cm.shape[1] != 3:
@@ -107,6 +105,7 @@ class _DeferredReflection(torch.autograd.Function):
                                                       ptr(refl_color), ptr(normal_world), stream_ptr(nv.device)),
                   "gsr_deferred_reflection_forward")
         ctx.save_for_backward(nv, bc, rs, cm, fv, cam)
+        ctx.sink = sink
         ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None instead of zero-filled [3,H,W] tensors
         return final, refl_color, normal_world
 
@@ -118,11 +117,14 @@ class _DeferredReflection(torch.autograd.Function):
         g_refl_color = None if g_refl_color is None else g_refl_color.float().contiguous()
         g_normal_world = None if g_normal_world is None else g_normal_world.float().contiguous()
         g_nv, g_base, g_s = torch.empty_like(nv), torch.empty_like(bc), torch.empty_like(rs)
-        # the library writes every element of both gradients.  With a gradient sink (set_reflection_grad_sink) they go
-        # straight into caller-owned tensors and autograd gets None: no allocation, no `grad += new` pass
-        sink = reflection_grad_sink or {}
+        # the library writes (or, accumulate mode, adds to) every element of both gradients.  With a sink they go straight
+        # into caller-owned tensors and autograd gets None: no allocation, no `grad += new` pass
+        sink = ctx.sink.tensors if ctx.sink is not None else {}
+        accumulate = ctx.sink is not None and ctx.sink.accumulate
         g_cm, g_fail = sink.get("cubemap"), sink.get("fail")
         sunk_cm, sunk_fail = g_cm is not None, g_fail is not None
+        if accumulate and not (sunk_cm and sunk_fail):
+            raise ValueError("reflection grad sink: accumulate=True needs both 'cubemap' and 'fail' tensors")
         for t, like, name in ((g_cm, cm, "cubemap"), (g_fail, fv, "fail")):
             if t is not None and (tuple(t.shape) != tuple(like.shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != like.device):
                 raise ValueError(f"reflection grad sink '{name}': expected contiguous float32 {tuple(like.shape)} on {like.device}")
@@ -131,50 +133,53 @@ class _DeferredReflection(torch.autograd.Function):
         n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=cm.device)
         with torch.cuda.device(nv.device):
-            check(lib.gsr_deferred_reflection_backward(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(g_final),
-                                                       ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base), ptr(g_s), ptr(g_cm),
-                                                       ptr(g_fail), ptr(scratch), n_scratch, stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
-        return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None
+            check(lib.gsr_deferred_reflection_backward_accum(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
+                                                             ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
+                                                             ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
+                                                             stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+        return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None, None
 
 
-# Optional gradient sink of the fused reflection op (not in the reference; the counterpart of GaussianRasterizer.set_grad_sink):
-# {"cubemap": float32 [6,3,L,L], "fail": float32 [3]} — e.g. views of gsr_dist.FlatGrads.  While set, the backward writes
-# THIS backward's cubemap / fail-value gradient into them (overwritten, not summed) and returns None to autograd.
-reflection_grad_sink = None
-
-
-def set_reflection_grad_sink(sink):
-    global reflection_grad_sink
-    reflection_grad_sink = dict(sink) if sink else None
-
-
-def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, world_view_transform, HWK, R, T):
+def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, world_view_transform, HWK, R, T, grad_sink=None,
+                        accumulate=False):
     """Fused pixel pass.  normal_view = allmap[2:5] (view space, un-normalised).  Returns
-    (final_image[3,H,W], refl_color[3,H,W], render_normal_world[3,H,W] normalised)."""
+    (final_image[3,H,W], refl_color[3,H,W], render_normal_world[3,H,W] normalised).
+
+    grad_sink (extension, the counterpart of GaussianRasterizer.set_grad_sink): {"cubemap": float32 [6,3,L,L],
+    "fail": float32 [3]} — e.g. views of gsr_dist.FlatGrads.  The backward of THIS call then writes (accumulate=False) or
+    adds (accumulate=True) the cubemap / fail-value gradient into them and returns None to autograd."""
     cam = _cam_block(world_view_transform, HWK, R, T)
+    sink = GradSink(grad_sink, accumulate) if grad_sink else None
     return _DeferredReflection.apply(normal_view, base_color, refl_strength_map, env_map.params['Cubemap_texture'],
-                                     env_map.params['Cubemap_failv'], cam)
+                                     env_map.params['Cubemap_failv'], cam, sink)
 
 
-def _ray_block(view):
-    """Device float[12] for gsr_surface_*: rays_d(x, y) = (x, y, 1) @ M (M = intrins^-1.T @ c2w[:3,:3].T, nine floats
-    row-major) and rays_o, built with the same tensor ops as utils/point_utils.py:9-23 and cached per camera."""
-    wvt, fpt = view.world_view_transform, view.full_proj_transform
-    W, H = int(view.image_width), int(view.image_height)
-    key = ("ray", wvt.data_ptr(), wvt._version, fpt.data_ptr(), fpt._version, W, H)
-    hit = _cam_cache.get(key)
-    if hit is not None:
-        return hit
-    dev = wvt.device
-    c2w = (wvt.T).inverse()
-    ndc2pix = torch.tensor([[W / 2, 0, 0, (W) / 2], [0, H / 2, 0, (H) / 2], [0, 0, 0, 1]]).float().to(dev).T
-    intrins = ((c2w.T @ fpt) @ ndc2pix)[:3, :3].T
-    M = intrins.inverse().T @ c2w[:3, :3].T
-    blk = torch.cat([M.reshape(-1), c2w[:3, 3].reshape(-1)]).float().contiguous()
-    if len(_cam_cache) > 256:
-        _cam_cache.clear()
-    _cam_cache[key] = blk
-    return blk
+class _ShadingNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, normal_view, cam):
+        nv = normal_view.float().contiguous()
+        out = torch.empty_like(nv)
+        with torch.cuda.device(nv.device):
+            check(lib.gsr_normal_world_forward(ptr(nv), ptr(cam), nv.shape[2], nv.shape[1], ptr(out), stream_ptr(nv.device)),
+                  "gsr_normal_world_forward")
+        ctx.save_for_backward(nv, cam)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nv, cam = ctx.saved_tensors
+        g_nv = torch.empty_like(nv)
+        g = g.float().contiguous()
+        with torch.cuda.device(nv.device):
+            check(lib.gsr_normal_world_backward(ptr(nv), ptr(cam), nv.shape[2], nv.shape[1], ptr(g), ptr(g_nv), stream_ptr(nv.device)),
+                  "gsr_normal_world_backward")
+        return g_nv, None
+
+
+def shading_normal(normal_view, world_view_transform, HWK, R, T):
+    """rend_normal of the reference: the blended view-space normal allmap[2:5] rotated to world space and divided by
+    (its length + 1e-6), as [3,H,W]."""
+    return _ShadingNormal.apply(normal_view, _cam_block(world_view_transform, HWK, R, T))
 
 
 class _SurfacePass(torch.autograd.Function):
@@ -208,149 +213,125 @@ class _SurfacePass(torch.autograd.Function):
 
 
 def surface_pass(allmap, view, depth_ratio):
-    """Fused form of gaussian_renderer/__init__.py:151-176 of the reference: returns (surf_depth[1,H,W],
-    surf_normal[3,H,W]) = (expected/median depth blend, depth_to_normal(surf_depth) * alpha.detach()) from the
-    rasterizer's allmap in one kernel; gradients flow to allmap[0], allmap[1] and allmap[5]."""
+    """Returns (surf_depth[1,H,W], surf_normal[3,H,W]): the blend of expected and median depth selected by `depth_ratio`, and
+    the pseudo-normal of that depth map (cross product of central differences of the unprojected points, zero on the
+    border) scaled by the detached alpha — from the rasterizer's allmap in one kernel.  Gradients flow to allmap[0],
+    allmap[1] and allmap[5]."""
     return _SurfacePass.apply(allmap, _ray_block(view), depth_ratio)
 
 
-def depths_to_points(view, depthmap):
-    """utils/point_utils.py:9-24"""
-    dev = depthmap.device
-    c2w = (view.world_view_transform.T).inverse()
-    W, H = view.image_width, view.image_height
-    ndc2pix = torch.tensor([[W / 2, 0, 0, (W) / 2], [0, H / 2, 0, (H) / 2], [0, 0, 0, 1]]).float().to(dev).T
-    projection_matrix = c2w.T @ view.full_proj_transform
-    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing='xy')
-    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
-    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3]
-    return depthmap.reshape(-1, 1) * rays_d + rays_o
-
-
-def depth_to_normal(view, depth):
-    """utils/point_utils.py:26-37"""
-    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
-    output = torch.zeros_like(points)
-    dx = torch.cat([points[2:, 1:-1] - points[:-2, 1:-1]], dim=0)
-    dy = torch.cat([points[1:-1, 2:] - points[1:-1, :-2]], dim=1)
-    normal_map = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
-    output[1:-1, 1:-1, :] = normal_map
-    return output
-
-
+# ------------------------------------------------------------------------------------------- the reference's entry points
 def _settings(viewpoint_camera, pc, bg_color, scaling_modifier):
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     return GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width), tanfovx=tanfovx, tanfovy=tanfovy,
-        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
         prefiltered=False, debug=False)
 
 
+def _precomputed_transmats(viewpoint_camera, pc, scaling_modifier, dev):
+    """pipe.compute_cov3D_python: the splat-to-pixel homographies formed on the host side and handed to the rasterizer as
+    cov3D_precomp (P,9), column-major: splat2world[:, (u, v, origin)] @ world2pix[:, (x, y, w)]."""
+    W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
+    near, far = viewpoint_camera.znear, viewpoint_camera.zfar
+    ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near], [0, 0, 0, 1]],
+                           dtype=torch.float32, device=dev).T
+    world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
+    keep = [0, 1, 3]
+    return (pc.get_covariance(scaling_modifier)[:, keep] @ world2pix[:, keep]).permute(0, 2, 1).reshape(-1, 9)
+
+
+def _sinks(pipe):
+    """Optional gradient sinks carried by the pipeline object (extension): pipe.gsr_grad_sink for the rasterizer,
+    pipe.gsr_reflection_grad_sink for the fused reflection op, pipe.gsr_accumulate for accumulate mode."""
+    return getattr(pipe, "gsr_grad_sink", None), getattr(pipe, "gsr_reflection_grad_sink", None), bool(getattr(pipe, "gsr_accumulate", False))
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, initial_stage=False,
            env_scope_center=[0.0, 0.0, 0.0], env_scope_radius=0.0):
-    """gaussian_renderer/__init__.py:42-219 of the reference.  Background tensor (bg_color) must be on GPU!"""
+    """Same contract as the reference's render().  Background tensor (bg_color) must be on GPU!"""
     xyz = pc.get_xyz
     dev = xyz.device
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
+    # zero tensor whose only purpose is to receive the screen-space gradient (densification statistic)
+    means2D = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
     try:
-        screenspace_points.retain_grad()
+        means2D.retain_grad()
     except Exception:
         pass
+    raster_sink, refl_sink, accumulate = _sinks(pipe)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
-    means3D = xyz
+    rasterizer.set_grad_sink(raster_sink, accumulate)
     if env_scope_radius > 0.0:
-        center = torch.tensor([float(c) for c in env_scope_center], device=dev)
-        env_scope_mask = torch.sum((xyz - center[None]) ** 2, dim=-1) < env_scope_radius ** 2
+        centre = torch.tensor([float(c) for c in env_scope_center], device=dev)
+        env_scope_mask = ((xyz - centre[None]) ** 2).sum(dim=-1) < env_scope_radius ** 2
     else:
-        env_scope_mask = torch.ones_like(xyz, device=dev) == 1.0
-    means2D = screenspace_points
-    opacity = pc.get_opacity
+        env_scope_mask = torch.ones_like(xyz, device=dev) == 1.0     # (P,3) all-true; the kernel reads entry [id]
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
-        splat2world = pc.get_covariance(scaling_modifier)
-        W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
-        near, far = viewpoint_camera.znear, viewpoint_camera.zfar
-        ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near], [0, 0, 0, 1]]).float().to(dev).T
-        world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
-        cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)  # column major
+        cov3D_precomp = _precomputed_transmats(viewpoint_camera, pc, scaling_modifier, dev)
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
-    shs = colors_precomp = None
-    if override_color is None:
-        shs = pc.get_features  # convert_SHs_python is force-disabled in the reference (:113)
-    else:
-        colors_precomp = override_color
-    refl_strengths = pc.get_refl
-
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    shs = pc.get_features if override_color is None else None       # SH evaluation always happens in the rasterizer
     base_color, radii, allmap, refl_strength_map, gaussian_weights = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, refl_strengths=refl_strengths, opacities=opacity,
+        means3D=xyz, means2D=means2D, shs=shs, colors_precomp=override_color, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask)
 
-    render_alpha = allmap[1:2]
-    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
-    render_depth_expected = allmap[0:1] / torch.clamp(render_alpha, min=1e-3)
-    render_depth_expected = torch.nan_to_num(render_depth_expected, 0, 0)
-    render_dist = allmap[6:7]
-    mask = allmap[7:8]
-    if getattr(pipe, "fused_surface", True):
-        surf_depth, surf_normal = surface_pass(allmap, viewpoint_camera, pipe.depth_ratio)
-    else:   # the reference's op chain (:151-176), kept for comparison
-        surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + (pipe.depth_ratio) * render_depth_median
-        surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-        surf_normal = surf_normal * (render_alpha).detach()
-
-    fused = getattr(pipe, "fused_reflection", True) and not initial_stage
-    if fused:
-        final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
-                                                                   viewpoint_camera.world_view_transform, viewpoint_camera.HWK,
-                                                                   viewpoint_camera.R, viewpoint_camera.T)
-    else:
-        render_normal = (allmap[2:5].permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T))
-        render_normal = render_normal / (torch.norm(render_normal, dim=-1, keepdim=True) + 1e-6)
-        rend_normal = render_normal.permute(2, 0, 1)
-        if not initial_stage:
-            refl_color = get_refl_color(pc.get_envmap, viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, render_normal)
-            final_image = (1 - refl_strength_map) * base_color + refl_strength_map * refl_color
-
-    out = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, 'rend_alpha': render_alpha,
-           'rend_normal': rend_normal, 'rend_dist': render_dist, 'surf_depth': surf_depth, 'surf_normal': surf_normal,
-           "gaussian_weights": gaussian_weights, 'env_scope_mask': mask}
+    surf_depth, surf_normal = surface_pass(allmap, viewpoint_camera, pipe.depth_ratio)
+    v = viewpoint_camera
+    out = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": allmap[1:2],
+           "rend_dist": allmap[6:7], "surf_depth": surf_depth, "surf_normal": surf_normal, "gaussian_weights": gaussian_weights,
+           "env_scope_mask": allmap[7:8]}
     if initial_stage:
+        out["rend_normal"] = shading_normal(allmap[2:5], v.world_view_transform, v.HWK, v.R, v.T)
         out["render"] = base_color
-    else:
-        out.update({"render": final_image, "refl_strength_map": refl_strength_map, "refl_color_map": refl_color,
-                    "base_color_map": base_color})
+        return out
+    final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
+                                                               v.world_view_transform, v.HWK, v.R, v.T, grad_sink=refl_sink,
+                                                               accumulate=accumulate)
+    out.update({"rend_normal": rend_normal, "render": final_image, "refl_strength_map": refl_strength_map, "refl_color_map": refl_color,
+                "base_color_map": base_color})
     return out
 
 
 def render_fast(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, initial_stage=False):
-    """gaussian_renderer/__init__.py:221-325 of the reference (inference path used by eval_fps.py / render.py)."""
+    """Inference path (the reference's render_fast, used by its eval_fps.py / render.py): all-true env-scope mask, no depth
+    or normal-consistency outputs."""
     xyz = pc.get_xyz
-    dev = xyz.device
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
+    means2D = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
-    env_scope_mask = torch.ones_like(xyz, device=dev).bool()
     base_color, _, allmap, refl_strength_map, _ = rasterizer(
-        means3D=xyz, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, refl_strengths=pc.get_refl,
-        opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None, env_scope_mask=env_scope_mask)
-    render_alpha = allmap[1:2]
-    if initial_stage or not getattr(pipe, "fused_reflection", True):
-        render_normal = (allmap[2:5].permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T))
-        render_normal = render_normal / (torch.norm(render_normal, dim=-1, keepdim=True) + 1e-6)
-        if initial_stage:
-            return {"render": base_color, 'rend_alpha': render_alpha, "rend_normal": render_normal.permute(2, 0, 1),
-                    "refl_strength_map": refl_strength_map}
-        refl_color = get_refl_color(pc.get_envmap, viewpoint_camera.HWK, viewpoint_camera.R, viewpoint_camera.T, render_normal)
-        final_image = (1 - refl_strength_map) * base_color + refl_strength_map * refl_color
-        rend_normal = render_normal.permute(2, 0, 1)
-    else:
-        final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
-                                                                   viewpoint_camera.world_view_transform, viewpoint_camera.HWK,
-                                                                   viewpoint_camera.R, viewpoint_camera.T)
-    return {"render": final_image, 'rend_alpha': render_alpha, 'rend_normal': rend_normal, "refl_strength_map": refl_strength_map,
+        means3D=xyz, means2D=means2D, shs=pc.get_features, colors_precomp=None, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
+        scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None, env_scope_mask=torch.ones_like(xyz).bool())
+    v = viewpoint_camera
+    if initial_stage:
+        return {"render": base_color, "rend_alpha": allmap[1:2], "refl_strength_map": refl_strength_map,
+                "rend_normal": shading_normal(allmap[2:5], v.world_view_transform, v.HWK, v.R, v.T)}
+    final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
+                                                               v.world_view_transform, v.HWK, v.R, v.T)
+    return {"render": final_image, "rend_alpha": allmap[1:2], "rend_normal": rend_normal, "refl_strength_map": refl_strength_map,
             "refl_color_map": refl_color, "base_color_map": base_color}
+
+
+def _panorama_dirs(H, W, device):
+    """The two latitude-longitude direction grids of the reference's environment-map visualisation: grid 1 is z-up with the
+    azimuth running over [-pi, pi] and the polar angle over [0, pi], end points included; grid 2 is y-up, sampled at pixel
+    centres, looking down -z at its centre column."""
+    az = torch.linspace(-math.pi, math.pi, W, dtype=torch.float32, device=device)[None, :]
+    po = torch.linspace(0.0, math.pi, H, dtype=torch.float32, device=device)[:, None]
+    grid1 = torch.stack([torch.sin(po) * torch.cos(az), torch.sin(po) * torch.sin(az), torch.cos(po).expand(H, W)], dim=-1)
+    th = math.pi * torch.linspace(1.0 / H, 1.0 - 1.0 / H, H, dtype=torch.float32, device=device)[:, None]
+    ph = math.pi * torch.linspace(-1.0 + 1.0 / W, 1.0 - 1.0 / W, W, dtype=torch.float32, device=device)[None, :]
+    grid2 = torch.stack([torch.sin(th) * torch.sin(ph), torch.cos(th).expand(H, W), -torch.sin(th) * torch.cos(ph)], dim=-1)
+    return grid1, grid2
+
+
+def render_env_map(pc, height=512, width=1024):
+    """The reference's render_env_map(): two [3,H,W] panoramas of sigmoid(environment cubemap), keys env_cood1 / env_cood2."""
+    env = pc.get_envmap
+    dev = env.params['Cubemap_texture'].device
+    out = {}
+    for name, dirs in zip(("env_cood1", "env_cood2"), _panorama_dirs(height, width, dev)):
+        rgb = torch.sigmoid(env(dirs.reshape(-1, 3)))
+        out[name] = rgb.reshape(height, width, 3).permute(2, 0, 1)
+    return out

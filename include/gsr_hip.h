@@ -77,6 +77,21 @@ int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int
                         const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
                         float* dL_dcolor, float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat,
                         float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream);
+/* Extension (no reference counterpart; the reference trains one view per step, train.py:134-150): the same call with one
+ * more switch.  accumulate != 0: the six PARAMETER gradients dL_dopacity, dL_drefl_strengths, dL_dmean3D, dL_dsh,
+ * dL_dscale, dL_drot are ADDED to the given tensors by the per-Gaussian kernel (stream-ordered read-add-write, no atomics)
+ * instead of written, so that several views of a batch accumulate into one gradient buffer on the device before ONE
+ * all-reduce (BASELINE config 4: 8 views over N GPUs).  The per-view outputs dL_dmean2D, dL_dnormal, dL_dcolor,
+ * dL_dtransMat are overwritten in both modes. */
+int gsr_surfel_backward_accum(int P, int D, int M, int R, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* refl_strengths, const float* scales, float scale_modifier, const float* rotations,
+                        const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                        void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                        const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                        float* dL_dcolor, float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat,
+                        float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate, int debug, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Variant G — 3D Gaussians with EWA projection, anti-aliasing and inverse depth.  Replaces
@@ -161,6 +176,21 @@ int gsr_deferred_reflection_backward(const float* normal_view, const float* base
                                      int width, int height, const float* g_final, const float* g_refl_color,
                                      const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
                                      float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats, void* stream);
+/* Extension: accumulate != 0 adds the cubemap / fail-value gradient to g_cubemap / g_fail instead of writing them
+ * (several views per optimizer step, see gsr_surfel_backward_accum). */
+int gsr_deferred_reflection_backward_accum(const float* normal_view, const float* base_color, const float* refl_strength,
+                                     const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
+                                     int width, int height, const float* g_final, const float* g_refl_color,
+                                     const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
+                                     float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
+                                     int accumulate, void* stream);
+/* Shading normal alone: out = normalize(normal_view rotated to world space) with the reference's +1e-6
+ * (gaussian_renderer/__init__.py:148,178-179), for the initial stage where render() skips the reflection chain but still
+ * returns rend_normal; `cam` as above (only its first nine floats are read).  The backward writes g_normal_view fully. */
+int gsr_normal_world_forward(const float* normal_view, const float* cam, int width, int height, float* out_normal_world,
+                             void* stream);
+int gsr_normal_world_backward(const float* normal_view, const float* cam, int width, int height,
+                              const float* g_normal_world, float* g_normal_view, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step passes around the rasterizer.

@@ -60,7 +60,9 @@ class HipSurfel:
     """Runs variant S through diff_surfel_rasterization on cuda:0 and exposes outputs, workspace
     arrays and gradients as numpy."""
 
-    def __init__(self, kw, requires_grad=True, scale_modifier=1.0, debug=False, prefiltered=False):
+    def __init__(self, kw, requires_grad=True, scale_modifier=1.0, debug=False, prefiltered=False, make_sink=None):
+        """make_sink(self) -> (sink dict, accumulate): called once the leaf tensors exist, before the forward (the gradient
+        sink of a rasterizer is bound to the forward calls made while it is set)."""
         import torch
         from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _RasterizeGaussians
         t = to_cuda(kw)
@@ -83,6 +85,8 @@ class HipSurfel:
                                            prefiltered=prefiltered, debug=debug)
         self.settings = st
         rast = GaussianRasterizer(st)
+        if make_sink is not None:
+            rast.set_grad_sink(*make_sink(self))
         self.color, self.radii, self.allmap, self.refl_map, self.gw = rast(
             means3D=self.means3D, means2D=self.means2D, opacities=self.opac, shs=self.shs, colors_precomp=self.colors,
             refl_strengths=self.refl, scales=self.scales, rotations=self.rots, cov3D_precomp=self.cov,

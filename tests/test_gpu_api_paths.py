@@ -182,32 +182,73 @@ def test_max_tile_id_bits_and_large_splats():
     assert psnr(hip.out()["color"], ref["color"]) >= 50
 
 
+def _sink_params(hip):
+    return dict(means3D=hip.means3D, shs=hip.shs, opacities=hip.opac, scales=hip.scales, rotations=hip.rots, refl_strengths=hip.refl)
+
+
+_GRAD_NAMES = dict(means3D="dL_dmeans3D", shs="dL_dsh", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations",
+                   refl_strengths="dL_drefl_strengths")
+
+
 def test_grad_sink_routes_gradients_into_caller_buffers():
-    """Extension: with a gradient sink set, the backward writes the parameter gradients into the caller's tensors
-    (views of one flat buffer) and autograd leaves the leaves' .grad alone; values equal the plain autograd path."""
-    from diff_surfel_rasterization import GaussianRasterizer
+    """Extension: with a gradient sink set on a rasterizer, the backward of ITS forward calls writes the parameter gradients
+    into the caller's tensors (views of one flat buffer) and autograd leaves the leaves' .grad alone; values equal the
+    plain autograd path.  A second rasterizer without a sink, run in between, is unaffected (no module-level state)."""
     from gsr_dist import FlatGrads
     kw, _, _ = scene_kwargs("S", 4000, 192, 128, 77, -2.8, 3, (0, 0, 0))
     g = S.make_upstream_grads(128, 192, 5)
     plain = HipSurfel(kw).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
-    hip = HipSurfel(kw)
-    params = dict(means3D=hip.means3D, shs=hip.shs, opacities=hip.opac, scales=hip.scales, rotations=hip.rots, refl_strengths=hip.refl)
-    fg = FlatGrads(params)
-    fg.flat.fill_(float("nan"))          # every element must be overwritten by the kernels
+    box = {}
+
+    def make_sink(hip):
+        box["fg"] = FlatGrads(_sink_params(hip))
+        box["fg"].flat.fill_(float("nan"))          # every element must be overwritten by the kernels
+        return box["fg"].sink(), False
+    hip = HipSurfel(kw, make_sink=make_sink)
+    other = HipSurfel(kw)                            # forward of another rasterizer while the first one's graph is alive
+    fg, params = box["fg"], _sink_params(hip)
     before = {k: p.grad.data_ptr() for k, p in params.items()}
-    GaussianRasterizer.set_grad_sink(fg.sink())
-    try:
-        hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
-    finally:
-        GaussianRasterizer.set_grad_sink(None)
-    names = dict(means3D="dL_dmeans3D", shs="dL_dsh", opacities="dL_dopacity", scales="dL_dscales", rotations="dL_drotations",
-                 refl_strengths="dL_drefl_strengths")
+    again = other.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    assert torch.isnan(fg.flat).all()                # the un-sunk rasterizer did not touch the first one's sink
+    hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
     for k, p in params.items():
         assert p.grad.data_ptr() == before[k]                      # still the flat-buffer view
         got = fg.view(k).cpu().numpy()
         assert np.isfinite(got).all(), k
-        ref = plain[names[k]].reshape(got.shape)
+        ref = plain[_GRAD_NAMES[k]].reshape(got.shape)
         assert rel_maxnorm(got, ref) <= 5e-5, k                    # atomics order differs run to run
+        assert rel_maxnorm(again[_GRAD_NAMES[k]].reshape(got.shape), ref) <= 5e-5, k
+
+
+def test_grad_sink_accumulates_views_on_the_device():
+    """accumulate=True: two views of the same scene add their parameter gradients into ONE zeroed buffer on the device
+    (kernel `+=`), equal to the sum of the two single-view backwards; overwrite mode would keep only the second."""
+    from gsr_dist import FlatGrads
+    kwa, _, _ = scene_kwargs("S", 3000, 160, 128, 78, -2.7, 3, (0, 0, 0))
+    kwb = dict(kwa)
+    camb = S.look_at_camera(160, 128, eye=(0.6, -0.2, -0.5))
+    for k in ("viewmatrix", "projmatrix", "campos"):
+        kwb[k] = camb[k]
+    g = S.make_upstream_grads(128, 160, 6)
+    ga = HipSurfel(kwa).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    gb = HipSurfel(kwb).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    box = {}
+
+    def make_sink(hip):
+        if "fg" not in box:
+            box["fg"] = FlatGrads(_sink_params(hip))
+        return box["fg"].sink(), True
+    ha = HipSurfel(kwa, make_sink=make_sink)
+    hb = HipSurfel(kwb, make_sink=make_sink)
+    ha.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    hb.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    for k in _GRAD_NAMES:
+        got = box["fg"].view(k).cpu().numpy()
+        ref = (ga[_GRAD_NAMES[k]] + gb[_GRAD_NAMES[k]]).reshape(got.shape)
+        assert rel_maxnorm(got, ref) <= 5e-5, k
+        assert rel_maxnorm(got, gb[_GRAD_NAMES[k]].reshape(got.shape)) > 1e-3, k     # really the sum, not the last view
+    with pytest.raises(ValueError):
+        HipSurfel(kwa, make_sink=lambda h: ({"means3D": box["fg"].view("means3D")}, True)).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
 
 
 def test_pixels_without_contributors_report_zero_median():

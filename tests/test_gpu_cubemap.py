@@ -154,9 +154,11 @@ def test_fused_deferred_reflection_vs_reference_chain(binned, monkeypatch):
 
 
 def test_fused_matches_composed_hip_path():
-    """The fused kernel and the un-fused composition (torch ops + CubemapEncoder HIP kernels) must agree."""
+    """The fused kernel and the un-fused composition (torch float32 ops on the GPU + the CubemapEncoder HIP kernels, chain in
+    tests/helpers_chain.py) must agree; so must the stand-alone shading-normal kernel of the initial stage."""
     from cubemapencoder import CubemapEncoder
-    from gaussian_renderer import deferred_reflection, get_refl_color
+    from gaussian_renderer import deferred_reflection, shading_normal
+    from helpers_chain import reflection_chain
     W, H, L = 200, 120, 32
     cam = S.make_camera(W, H)
     ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
@@ -166,13 +168,21 @@ def test_fused_matches_composed_hip_path():
     s = torch.rand(1, H, W, generator=g).cuda()
     enc = CubemapEncoder(output_dim=3, resolution=L).cuda()
     f_h, c_h, n_h = deferred_reflection(nv, base, s, enc, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
-    rn = (nv.permute(1, 2, 0) @ (ct["viewmatrix"][:3, :3].T))
-    rn = rn / (torch.norm(rn, dim=-1, keepdim=True) + 1e-6)
-    c_c = get_refl_color(enc, (H, W, cam["K"]), ct["R"], ct["T"], rn)
-    f_c = (1 - s) * base + s * c_c
+    f_c, c_c, n_c = reflection_chain(nv, base, s, enc, ct["viewmatrix"], H, W, cam["K"], ct["R"], ct["T"])
     # float32 on both sides; a direction a few ulps apart may pick neighbouring texel weights: tolerance, not bit equality
     assert (torch.abs(f_h - f_c) > 1e-3).float().mean().item() <= 1e-3
-    assert (torch.abs(n_h - rn.permute(2, 0, 1)) > 1e-5).float().mean().item() == 0.0
+    assert (torch.abs(n_h - n_c) > 1e-5).float().mean().item() == 0.0
+    # initial stage: shading normal alone, forward and backward against the torch chain
+    nv1 = nv.clone().requires_grad_(True)
+    nv2 = nv.clone().requires_grad_(True)
+    w = torch.randn(3, H, W, generator=g).cuda()
+    n1 = shading_normal(nv1, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+    (n1 * w).sum().backward()
+    _, _, n2 = reflection_chain(nv2, base, s, enc, ct["viewmatrix"], H, W, cam["K"], ct["R"], ct["T"])
+    (n2 * w).sum().backward()
+    assert (n1.detach() - n_h).abs().max().item() <= 1e-6      # two kernels, same formula (contraction may differ)
+    assert (n1 - n2).abs().max().item() <= 1e-5
+    assert rel_maxnorm(nv1.grad.cpu().numpy(), nv2.grad.cpu().numpy()) <= 1e-4
 
 
 @pytest.mark.parametrize("L,W,H", [(128, 320, 200), (256, 320, 200), (600, 160, 96), (256, 64, 64), (16, 333, 77)])
@@ -221,10 +231,10 @@ def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
 
 
 def test_reflection_grad_sink_routes_cubemap_gradients():
-    """Extension: with a reflection gradient sink the cubemap / fail-value gradients land in the caller's tensors
-    (overwritten: the buffers start as NaN) and autograd leaves the leaves' .grad alone."""
-    import gaussian_renderer
-    from gaussian_renderer import deferred_reflection, set_reflection_grad_sink
+    """Extension: with a gradient sink the cubemap / fail-value gradients of THAT call land in the caller's tensors
+    (overwritten: the buffers start as NaN; or added in accumulate mode) and autograd leaves the leaves' .grad alone;
+    a call without a sink made in between is unaffected (the sink is per call, there is no module state)."""
+    from gaussian_renderer import deferred_reflection
     W, H, L = 160, 96, 16
     cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
     ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
@@ -238,22 +248,29 @@ def test_reflection_grad_sink_routes_cubemap_gradients():
     class Env:
         pass
 
-    def run(sink):
+    def run(sink, accumulate=False, scale=1.0):
         tex = torch.from_numpy(tex0).cuda().requires_grad_(True)
         fail = torch.from_numpy(fail0).cuda().requires_grad_(True)
         env = Env()
         env.params = {"Cubemap_texture": tex, "Cubemap_failv": fail}
-        set_reflection_grad_sink(sink)
-        try:
-            f, _, _ = deferred_reflection(nv, base, strength, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
-            (f * wf).sum().backward()
-        finally:
-            set_reflection_grad_sink(None)
+        f, _, _ = deferred_reflection(nv, base, strength, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"], grad_sink=sink,
+                                      accumulate=accumulate)
+        (f * wf * scale).sum().backward()
         return tex, fail
     tex_p, fail_p = run(None)
     sink = {"cubemap": torch.full((6, 3, L, L), float("nan"), device="cuda"), "fail": torch.full((3,), float("nan"), device="cuda")}
     tex_s, fail_s = run(sink)
+    tex_q, fail_q = run(None)           # no sink on this call: plain autograd again
     assert tex_s.grad is None and fail_s.grad is None
+    assert rel_maxnorm(tex_q.grad.cpu().numpy(), tex_p.grad.cpu().numpy()) <= 1e-5      # (atomics order differs run to run)
     assert torch.isfinite(sink["cubemap"]).all() and torch.isfinite(sink["fail"]).all()
     assert rel_maxnorm(sink["cubemap"].cpu().numpy(), tex_p.grad.cpu().numpy()) <= 1e-5
     np.testing.assert_allclose(sink["fail"].cpu().numpy(), fail_p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # accumulate: zero once, two backwards (weights 1 and 0.5) add up on the device
+    acc = {"cubemap": torch.zeros((6, 3, L, L), device="cuda"), "fail": torch.zeros((3,), device="cuda")}
+    run(acc, accumulate=True)
+    run(acc, accumulate=True, scale=0.5)
+    assert rel_maxnorm(acc["cubemap"].cpu().numpy(), 1.5 * tex_p.grad.cpu().numpy()) <= 1e-5
+    np.testing.assert_allclose(acc["fail"].cpu().numpy(), 1.5 * fail_p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        run({"cubemap": acc["cubemap"]}, accumulate=True)

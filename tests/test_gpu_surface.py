@@ -1,5 +1,5 @@
 """GPU parity of the fused surface pass through the C ABI against the torch-autograd golden vectors
-and the oracle, and of render() with the fused pass against render() with the reference's torch op chain.
+and the oracle, and of render() against the torch chain of tests/helpers_chain.py on the rasterizer's allmap.
 Tolerances: surf_depth 1e-5 relative, surf_normal 2e-4 absolute (unit vectors from fp32 differences of points ~5 units
 apart), gradients 1e-3 of the tensor's max (the cross product of two fp32 central differences cancels ~3 digits)."""
 import os
@@ -74,10 +74,14 @@ def test_surface_pass_1080p_properties_and_oracle_sample():
     assert am.grad[5].abs().max() == 0 and torch.isfinite(am.grad).all() and am.grad[0].abs().max() > 0
 
 
-def test_render_fused_surface_equals_reference_op_chain():
-    """render() end to end on a small scene: fused surface pass vs the torch op chain of the reference (both on the GPU)."""
+def test_render_surface_outputs_equal_torch_chain():
+    """render() end to end on a small scene: its surf_depth / surf_normal / rend_normal (fused HIP passes) against the torch
+    chain of tests/helpers_chain.py evaluated on the rasterizer's own allmap, values and gradients through to the
+    parameters (both on the GPU, float32)."""
     import gsr_synth as S
-    from gaussian_renderer import render
+    from diff_surfel_rasterization import GaussianRasterizer
+    from gaussian_renderer import _settings, render
+    from helpers_chain import shading_normal_chain, surface_chain
     P, W, H = 4000, 128, 96
     sc = S.make_scene(P, "S", seed=31, mu=-2.6)
     tex, fail = S.make_cubemap(16, 3, 31)
@@ -91,6 +95,9 @@ def test_render_fused_surface_equals_reference_op_chain():
         HWK, R, T = (H, W, cam["K"]), ct["R"], ct["T"]
         znear, zfar = 0.01, 100.0
 
+    class Pipe:
+        depth_ratio, compute_cov3D_python = 0.3, False
+
     def model():
         t = {k: torch.from_numpy(sc[k]).cuda().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths")}
 
@@ -103,17 +110,51 @@ def test_render_fused_surface_equals_reference_op_chain():
             active_sh_degree, get_envmap = 3, Env
         return PC, t
 
+    bg = torch.zeros(3, device="cuda")
     outs = []
-    for fused in (True, False):
-        class Pipe:
-            depth_ratio, compute_cov3D_python, fused_reflection, fused_surface = 0.3, False, True, fused
+    for initial_stage in (False, True):
         PC, t = model()
-        pkg = render(View, PC, Pipe, torch.zeros(3, device="cuda"))
-        loss = (pkg["surf_normal"] * pkg["rend_normal"]).sum() + pkg["surf_depth"].mean()
-        loss.backward()
-        outs.append((pkg["surf_depth"].detach(), pkg["surf_normal"].detach(), {k: v.grad.clone() for k, v in t.items()}))
-    (sd_a, sn_a, g_a), (sd_b, sn_b, g_b) = outs
-    assert torch.allclose(sd_a, sd_b, rtol=1e-5, atol=1e-6)
-    assert (sn_a - sn_b).abs().max().item() < 5e-4
-    for k in g_a:
-        assert (g_a[k] - g_b[k]).abs().max().item() <= 2e-3 * g_b[k].abs().max().item() + 1e-9, k
+        pkg = render(View, PC, Pipe, bg, initial_stage=initial_stage)
+        ((pkg["surf_normal"] * pkg["rend_normal"]).sum() + pkg["surf_depth"].mean()).backward()
+        outs.append((pkg["surf_depth"].detach(), pkg["surf_normal"].detach(), pkg["rend_normal"].detach(), {k: v.grad.clone() for k, v in t.items()}))
+        assert ("refl_color_map" in pkg) == (not initial_stage)
+    # the same quantities through the torch chain on the rasterizer's allmap
+    PC, t = model()
+    rast = GaussianRasterizer(raster_settings=_settings(View, PC, bg, 1.0))
+    _, _, allmap, _, _ = rast(means3D=t["means3D"], means2D=torch.zeros(P, 3, device="cuda", requires_grad=True), shs=t["shs"],
+                              refl_strengths=t["refl_strengths"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                              env_scope_mask=torch.ones(P, dtype=torch.bool, device="cuda"))
+    sd_c, sn_c = surface_chain(allmap, ct["viewmatrix"], ct["projmatrix"], Pipe.depth_ratio)
+    rn_c = shading_normal_chain(allmap[2:5], ct["viewmatrix"]).permute(2, 0, 1)
+    ((sn_c * rn_c).sum() + sd_c.mean()).backward()
+    g_c = {k: v.grad.clone() for k, v in t.items()}
+    for sd, sn, rn, g in outs:
+        assert torch.allclose(sd, sd_c.detach(), rtol=1e-5, atol=1e-6)
+        assert (sn - sn_c.detach()).abs().max().item() < 5e-4
+        assert (rn - rn_c.detach()).abs().max().item() < 1e-5
+        for k in g:
+            assert (g[k] - g_c[k]).abs().max().item() <= 2e-3 * g_c[k].abs().max().item() + 1e-9, k
+
+
+def test_camera_blocks_are_rebuilt_for_new_cameras():
+    """Cameras created and freed in a loop (per-frame cameras of a video / viewer loop) get their own camera constants even
+    when the allocator hands a new camera the addresses of a freed one: the fused reflection must follow the camera."""
+    import gsr_synth as S
+    from gaussian_renderer import deferred_reflection
+    from helpers_chain import reflection_chain
+    from cubemapencoder import CubemapEncoder
+    W, H = 96, 64
+    g = torch.Generator().manual_seed(8)
+    nv = torch.randn(3, H, W, generator=g).cuda()
+    base, s = torch.rand(3, H, W, generator=g).cuda(), torch.rand(1, H, W, generator=g).cuda()
+    enc = CubemapEncoder(output_dim=3, resolution=16).cuda()
+    seen = set()
+    for k in range(6):
+        cam = S.look_at_camera(W, H, eye=(0.5 * k - 1.0, 0.2 * k, -3.0 - 0.3 * k))
+        ct = {kk: torch.from_numpy(np.ascontiguousarray(v)).cuda() for kk, v in cam.items() if isinstance(v, np.ndarray)}
+        seen.add(ct["viewmatrix"].data_ptr())
+        f_h, _, n_h = deferred_reflection(nv, base, s, enc, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+        f_c, _, n_c = reflection_chain(nv, base, s, enc, ct["viewmatrix"], H, W, cam["K"], ct["R"], ct["T"])
+        assert (n_h - n_c).abs().max().item() <= 1e-5, k
+        assert (torch.abs(f_h - f_c) > 1e-3).float().mean().item() <= 2e-3, k
+        del ct, f_h, n_h, f_c, n_c

@@ -162,21 +162,19 @@ def test_train_state_step_end_to_end():
                                              projmatrix=ct["projmatrix"], sh_degree=3, campos=ct["campos"], prefiltered=False, debug=False)
     rast = GaussianRasterizer(settings)
     sink = st.grads.sink()
-    GaussianRasterizer.set_grad_sink(sink)
-    try:
-        class Env:
-            params = {"Cubemap_texture": st.p["cubemap"], "Cubemap_failv": st.p["fail"]}
-        means2D = torch.zeros(P, 3, device="cuda", requires_grad=True)
-        base, radii, allmap, refl_map, gw = rast(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"], shs=st.p["shs"],
-                                                 refl_strengths=st.p["refl_strengths"], scales=st.p["scales"], rotations=st.p["rotations"],
-                                                 env_scope_mask=torch.from_numpy(sc["env_scope_mask"]).cuda())
-        final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, Env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
-        gt = torch.rand(3, H, W, device="cuda")
-        st.grads.zero_except_(sink)
-        loss = photometric_loss(final, gt, 0.2)
-        loss.backward()
-    finally:
-        GaussianRasterizer.set_grad_sink(None)
+    rast.set_grad_sink(sink)
+
+    class Env:
+        params = {"Cubemap_texture": st.p["cubemap"], "Cubemap_failv": st.p["fail"]}
+    means2D = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    base, radii, allmap, refl_map, gw = rast(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"], shs=st.p["shs"],
+                                             refl_strengths=st.p["refl_strengths"], scales=st.p["scales"], rotations=st.p["rotations"],
+                                             env_scope_mask=torch.from_numpy(sc["env_scope_mask"]).cuda())
+    final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, Env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+    gt = torch.rand(3, H, W, device="cuda")
+    st.grads.zero_except_(sink)
+    loss = photometric_loss(final, gt, 0.2)
+    loss.backward()
     assert torch.isfinite(st.grads.flat).all()
     st.update_learning_rate(1)
     st.optimizer.step()
@@ -220,7 +218,7 @@ def test_training_loop_converges_and_survives_densification():
         znear, zfar = 0.01, 100.0
 
     class Pipe:
-        depth_ratio, compute_cov3D_python, fused_reflection, fused_surface = 0.0, False, True, True
+        depth_ratio, compute_cov3D_python = 0.0, False
 
     def model_of(st):
         class Env:
