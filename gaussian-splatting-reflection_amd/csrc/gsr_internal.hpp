@@ -229,6 +229,59 @@ __device__ __forceinline__ float wave_max_pos(float v) {
 	return v;
 }
 
+// ---- lane masks.  A per-lane predicate lives in an SGPR pair; the tile kernels keep their predicates as explicit 64-bit
+// masks (`lmask`: ballots of single compares combined with scalar and/or/andn2) and select with v_cndmask on that pair.
+// Written out because `__ballot(a && b)` makes hipcc materialise the combined predicate in a VGPR and compare it again
+// (v_cndmask 0/1 + v_cmp_ne, two ~4-cycle instructions per ballot) although the SGPR pair is already the answer when all
+// 64 lanes are active, which they always are in these kernels.
+typedef unsigned long long lmask;
+#define LMASK(cond) __builtin_amdgcn_ballot_w64(cond)      // `cond` must be ONE compare for the fold to v_cmp -> sgpr pair
+__device__ __forceinline__ float selm(lmask m, float a, float b) {   // lane bit set ? a : b
+	float r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+	return r;
+}
+__device__ __forceinline__ float selm0(lmask m, float a) {           // lane bit set ? a : 0
+	float r;
+	asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+	return r;
+}
+__device__ __forceinline__ uint32_t selmu(lmask m, uint32_t a, uint32_t b) {
+	uint32_t r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+	return r;
+}
+
+// fminf without the canonicalising v_max(x, x) hipcc puts in front of v_min_f32 when it cannot prove an operand is not a
+// signalling NaN (results of fp32 arithmetic never are): one ~4-cycle instruction per use in the pair loops.
+__device__ __forceinline__ float min_raw(float a, float b) {
+	float r;
+	asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+// Row maxima of four non-negative values (one per processed pair) in 8 DPP instructions: the max-flavoured twin of
+// row_reduce_groups + quad_sum.  On return every lane of quad q of a 16-lane row holds the ROW maximum of value
+// {a, c, b, d}[q] (row_reduce_slot).  All 64 lanes must be active.
+__device__ __forceinline__ float row_max4(float a, float b, float c, float d) {
+	float p, q, z;
+	asm volatile("s_nop 1\n\t"
+	             "v_max_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+	             "v_max_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+	             "v_max_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+	             "v_max_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+	             : "=&v"(p), "=&v"(q) : "v"(a), "v"(b), "v"(c), "v"(d));
+	asm volatile("s_nop 1\n\t"
+	             "v_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+	             "v_max_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+	             "s_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\t"
+	             "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+	             : "=&v"(z) : "v"(p), "v"(q));
+	return z;
+}
+
 // exp(x) for x in [-88, 0]: exp2 of a two-float product x*log2(e) (hi from the multiply, lo from the FMA residual
 // plus the low word of log2(e)) with a first-order correction for lo.  ~1.5 ulp, 5 instructions; the plain
 // exp2(x*log2e) form loses |x| * 2^-24 relative (3e-7 at x = -5.5), which the ill-conditioned surfel backward

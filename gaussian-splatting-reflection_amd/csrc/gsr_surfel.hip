@@ -307,6 +307,14 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // previous one is still being blended; (3) the per-surfel max blend weight goes out with one atomic per
 // touched surfel.  The wave stops as soon as ITS 64 pixels are saturated: no workgroup barriers, no waiting
 // for the other three quadrants (the reference synchronises the 256 threads of a tile twice per batch).
+//
+// Instruction budget (tests/microbench/inst_cost.hip, MI355X, per wave64 instruction and SIMD, 4-8 waves resident): plain
+// VGPR-operand VOP2/VOP3 ~1.1 ns; anything that reads an SGPR, v_min/v_max/v_cmp/v_cndmask, DPP, packed fp32 and SALU
+// ~1.85 ns; v_exp/v_rcp 3.6 ns.  The pair loop is bound by that issue rate (adding resident waves changes nothing), so
+// it is written to MINIMISE THE COUNT of ~1.85-ns instructions: predicates are explicit lane masks (no VGPR
+// materialisation for ballots), the rare `unstable` case leaves the straight-line path through a wave-uniform branch,
+// the 64-lane max for gaussian_weights is done for four pairs at a time (row_max4: 2 DPP per pair instead of 6 + 6 nops),
+// the env-scope plane is an accumulated weight, and the median bookkeeping stops once no pixel has T > 0.5.
 #define S_WBATCH 64
 #define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
 #ifndef S_SUB
@@ -320,6 +328,83 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 #else
 #define GSR_FWD_ATTR
 #endif
+
+// Per-pixel compositing state of the forward wave.
+struct SurfelFwdPix {
+	float T, C2, M2, distortion, median_depth, median_contributor, maskacc;
+	v2f Crg, Nxy, NzR, DM;          // accumulators paired like the record: (r, g) | (n.x, n.y) | (n.z, refl) | (depth, m)
+	uint32_t last_contributor;
+};
+
+// One (wave, surfel) pair of the forward.  `done` = lanes whose pixel has retired (or lies outside the image); returns the
+// lanes that blended (ok) and updates `done`.  wq receives the blend weight (0 where the pair did not contribute).
+__device__ __forceinline__ lmask surfel_fwd_pair(const SurfelRec& R, const v2f pix, uint32_t contributor, bool med_live, SurfelFwdPix& st,
+                                                 lmask& done, float& wq) {
+	float sx, sy, rho3d, depth, alpha, rho2d;
+	{
+#pragma clang fp contract(off)
+		// Plain IEEE mul/sub in the reference's textual order (contraction off): the plane/plane cross product cancels
+		// catastrophically in fp32, so the evaluation order is part of the result (see surfel_pair).
+		const v2f Tw = R.Twxy();
+		const v2f X = pix * Tw.x - R.TuvX();          // k.x = pix.x*Tw.x - Tu.x | l.x = pix.y*Tw.x - Tv.x
+		const v2f Y = pix * Tw.y - R.TuvY();
+		const v2f Z = pix * R.Twz() - R.TuvZ();
+		const v2f a = Y * Z.yx;                       // (k.y*l.z, l.y*k.z)
+		const v2f b = Z * X.yx;                       // (k.z*l.x, l.z*k.x)
+		const v2f c = X * Y.yx;                       // (k.x*l.y, l.x*k.y)
+		const float ppx = a.x - a.y, ppy = b.x - b.y, pz = c.x - c.y;   // scalar subtractions: no register shuffles
+		const lmask unstable = LMASK(fabsf(pz) < 1e-4f);
+		if (__builtin_expect(unstable == 0ull, 1)) {
+			const float inv = div_nr(1.0f, pz);
+			sx = ppx * inv; sy = ppy * inv;
+			rho3d = sx * sx + sy * sy;
+		} else {                                      // some lane's ray grazes the splat plane: the reference's select form
+			const float inv = div_nr(1.0f, selm(unstable, 1.0f, pz));
+			sx = selm(unstable, 0.f, ppx * inv); sy = selm(unstable, 0.f, ppy * inv);
+			rho3d = selm(unstable, 1e8f, sx * sx + sy * sy);
+		}
+		const v2f d = R.xy() - pix;
+		const v2f d2 = d * d;
+		rho2d = S_FILTER_INV_SQ * (d2.x + d2.y);
+		const v2f st2 = mk2(sx, sy) * Tw;
+		depth = (st2.x + st2.y) + R.Twz();
+	}
+	const float power = -0.5f * min_raw(rho3d, rho2d);
+	alpha = fminf(0.99f, R.opac() * exp_neg(power));
+	// reference order of the tests: depth < near, power > 0, alpha < 1/255 (DSR forward.cu:394-410).  power = -rho/2 with
+	// rho >= 0 is never > 0 (and a NaN compares false both here and there), so that test has no instruction.
+	const lmask live = LMASK(!(depth < S_NEAR)) & LMASK(!(alpha < 1.0f / 255.0f)) & ~done;
+	const float test_T = st.T * (1 - alpha);
+	const lmask sat = LMASK(test_T < 0.0001f) & live;   // this pixel is saturated: the pair is dropped and the pixel retires
+	const lmask ok = live & ~sat;
+	done |= sat;
+	wq = 0.f;
+	if (ok != 0ull) {
+		const float w = selm0(ok, alpha * st.T);
+		const float dep = selm(ok, depth, 1.0f);
+		const float A = 1 - st.T;
+		const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(dep));
+		const v2f w2 = mk2(w, w);
+		st.distortion += (m * m * A + st.M2 - 2 * m * st.DM.y) * w;
+		st.M2 += m * (m * w);
+		st.DM = __builtin_elementwise_fma(mk2(dep, m), w2, st.DM);        // depth sum, M1
+		if (med_live) {                                                  // median depth: last pair seen while T > 0.5
+			const lmask med = ok & LMASK(st.T > 0.5f);
+			st.median_depth = selm(med, dep, st.median_depth);
+			st.median_contributor = selm(med, (float)contributor, st.median_contributor);
+		}
+		st.Nxy = __builtin_elementwise_fma(R.nxy(), w2, st.Nxy);
+		st.NzR = __builtin_elementwise_fma(mk2(R.nz(), R.refl()), w2, st.NzR);
+		st.Crg = __builtin_elementwise_fma(R.rg(), w2, st.Crg);
+		st.C2 = fmaf(R.b(), w, st.C2);
+		st.maskacc = fmaf(R.mask(), w, st.maskacc);   // > 0 iff a contributor inside the env scope blended (w > 0 for every ok pair)
+		st.T = selm(ok, test_T, st.T);
+		st.last_contributor = selmu(ok, contributor, st.last_contributor);
+		wq = w;
+	}
+	return ok;
+}
+
 __global__ void __launch_bounds__(64) GSR_FWD_ATTR
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
@@ -334,25 +419,28 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 	if (bx0 >= W || by0 >= H) return;
 	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
-	const float pixx = (float)px, pixy = (float)py;
+	const v2f pix = mk2((float)px, (float)py);
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
 	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
 	__shared__ uint32_t s_hid[S_WBATCH];
-	__shared__ uint32_t s_hj[S_WBATCH];
-	__shared__ float s_wmax[S_WBATCH];
+	__shared__ uint32_t s_hc[S_WBATCH];
+	__shared__ float4 s_wmax[S_WBATCH];            // [hit][16-lane row]: row maxima of the blend weight
 
-	bool done = !inside;
-	float T = 1.0f;
-	uint32_t last_contributor = 0;
-	// accumulators paired like the record: (r, g), b | (n.x, n.y), (n.z, refl) | (depth, m)
-	v2f Crg = mk2(0.f, 0.f), Nxy = mk2(0.f, 0.f), NzR = mk2(0.f, 0.f), DM = mk2(0.f, 0.f);
-	float C2 = 0, mask = 0, M2 = 0, distortion = 0, median_depth = 0;
-	float median_contributor = -1.0f;
+	lmask done = ~LMASK(px < W) | ~LMASK(py < H);  // lanes outside the image never blend
+	SurfelFwdPix st;
+	st.T = 1.0f;
+	st.C2 = st.M2 = st.distortion = st.median_depth = st.maskacc = 0.f;
+	st.median_contributor = -1.0f;
+	st.Crg = st.Nxy = st.NzR = st.DM = mk2(0.f, 0.f);
+	st.last_contributor = 0;
+	bool med_live = true;
+	// (hit ordinal + value slot of this lane's quad) * 16 bytes + row * 4: where the lane parks a row maximum (row_max4)
+	const uint32_t wmax_off = (uint32_t)row_reduce_slot(lane) * 16u + (uint32_t)(lane >> 4) * 4u;
 
 	for (int base = 0; base < count; base += S_WBATCH) {
-		if (__ballot(!done) == 0ull) break;
+		if (done == ~0ull) break;
 		const int nb = min(S_WBATCH, count - base);
 		// ---- 1. vote
 		bool hit = lane < nb;
@@ -366,101 +454,93 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
+		s_wmax[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 		if (hit) {
 			const int k = __popcll(mm & ((1ull << lane) - 1ull));
 			s_hid[k] = id;
-			s_hj[k] = (uint32_t)lane;
+			s_hc[k] = (uint32_t)(base + lane + 1);     // the pair's contributor number (1-based position in the tile's list)
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
-		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
+		const uint32_t hc = lane < nh ? s_hc[lane] : 0u;
 		// ---- 2. blend.  Two SGPR record buffers ping-pong (as in the backward): the s_load of the next record is issued
-		// right after the ray-splat evaluation of the current one; with a single rotating buffer the compiler copies the 20
-		// SGPRs twice per pair (~25 of the ~60 scalar instructions per pair, and SALU issue is as scarce as VALU issue).
-		unsigned long long touched = 0ull;
+		// right after the arithmetic of the current one has started; with a single rotating buffer the compiler copies the 20
+		// SGPRs twice per pair.  Four pairs per trip: their blend weights share one packed row-max reduction.
 		using Rec = SurfelRec;
 		auto fetch = [&](int k) -> Rec {
 			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
 		};
-		// returns true when every pixel of the block has retired
-		auto blend = [&](int k, const Rec& R, auto&& prefetch_next) -> bool {
-			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
-			// straight-line for all 64 lanes: a lane whose pair does not contribute blends with weight 0 (the identity of
-			// every accumulator) instead of sitting out in an exec-mask region
-			SurfelPair o;
-			const bool pair_ok = surfel_pair<true>(R, pixx, pixy, o);
-			__builtin_amdgcn_sched_barrier(0);
-			prefetch_next();
-			__builtin_amdgcn_sched_barrier(0);
-			const float test_T = T * (1 - o.alpha);
-			const bool live = !done && pair_ok;
-			const bool sat = live && test_T < 0.0001f;   // this pixel is saturated: the pair is dropped and the pixel retires
-			const bool ok = live && !sat;
-			done = done || sat;
-			if (__ballot(ok) != 0ull) {
-				const float w = ok ? o.alpha * T : 0.f;
-				const float depth = ok ? o.depth : 1.0f;
-				const float A = 1 - T;
-				const float m = S_FAR / (S_FAR - S_NEAR) * (1 - S_NEAR * __builtin_amdgcn_rcpf(depth));
-				const v2f w2 = mk2(w, w);
-				distortion += (m * m * A + M2 - 2 * m * DM.y) * w;
-				M2 += m * (m * w);
-				DM = __builtin_elementwise_fma(mk2(depth, m), w2, DM);        // depth sum, M1
-				const bool med = ok && T > 0.5f;
-				median_depth = med ? depth : median_depth;
-				median_contributor = med ? (float)contributor : median_contributor;
-				Nxy = __builtin_elementwise_fma(R.nxy(), w2, Nxy);
-				NzR = __builtin_elementwise_fma(mk2(R.nz(), R.refl()), w2, NzR);
-				Crg = __builtin_elementwise_fma(R.rg(), w2, Crg);
-				C2 = fmaf(R.b(), w, C2);
-				mask = (ok && R.mask() != 0.f) ? 1.0f : mask;
-				T = ok ? test_T : T;
-				last_contributor = ok ? contributor : last_contributor;
-				// gaussian_weights (forward.cu:458-459): max over the wave's pixels; merged across waves by atomicMax
-				const float wm = wave_max_pos(w);
-				if (lane == 63) s_wmax[k] = wm;
-				touched |= 1ull << k;
-			}
-			return __ballot(sat) != 0ull && __ballot(!done) == 0ull;
-		};
 		Rec A = fetch(0), B = A;
-		for (int k = 0; k < nh; k += 2) {
-			if (blend(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); })) break;
-			if (k + 1 >= nh) break;
-			if (blend(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); })) break;
+		for (int k = 0; k < nh; k += 4) {
+			float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+			lmask any = 0ull;
+			bool stop;
+			{
+				const uint32_t c = __builtin_amdgcn_readlane(hc, k);
+				if (k + 1 < nh) B = fetch(k + 1);
+				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w0);
+				stop = done == ~0ull || k + 1 >= nh;
+			}
+			if (!stop) {
+				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 1);
+				if (k + 2 < nh) A = fetch(k + 2);
+				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w1);
+				stop = done == ~0ull || k + 2 >= nh;
+			}
+			if (!stop) {
+				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 2);
+				if (k + 3 < nh) B = fetch(k + 3);
+				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w2);
+				stop = done == ~0ull || k + 3 >= nh;
+			}
+			if (!stop) {
+				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 3);
+				if (k + 4 < nh) A = fetch(k + 4);
+				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w3);
+				stop = done == ~0ull;
+			}
+			if (any != 0ull) {
+				// gaussian_weights (forward.cu:458-459): row maxima of the four weights; the rows are merged in step 3
+				const float z = row_max4(w0, w1, w2, w3);
+				reinterpret_cast<float*>(s_wmax)[(k * 16 + wmax_off) >> 2] = z;   // the four lanes of a quad store the same value
+				med_live = med_live && LMASK(st.T > 0.5f) != 0ull;
+			}
+			if (stop) break;
 		}
 		__syncthreads();
 		// ---- 3. w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
 		// check-then-atomicExch is racy, this is the true maximum
-		if (lane < nh && ((touched >> lane) & 1ull)) {
-			const float m = s_wmax[lane];
+		if (lane < nh) {
+			const float4 r = s_wmax[lane];
+			const float m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
 			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + hid, __float_as_int(m));
 		}
 		__syncthreads();
 	}
 	if (inside) {
 		const size_t HW = (size_t)H * W;
-		const size_t pix = (size_t)W * py + px;
-		final_T[pix] = T;
-		final_T[HW + pix] = DM.y;
-		final_T[2 * HW + pix] = M2;
-		n_contrib[pix] = last_contributor;
+		const size_t p = (size_t)W * py + px;
+		const float T = st.T;
+		final_T[p] = T;
+		final_T[HW + p] = st.DM.y;
+		final_T[2 * HW + p] = st.M2;
+		n_contrib[p] = st.last_contributor;
 		// the reference converts the float -1 of "no median" with cvt.rzi.u32.f32, which saturates to 0; in C++ that
 		// conversion is undefined (and clang does exploit it), so the clamp is explicit
-		n_contrib[HW + pix] = (uint32_t)fmaxf(median_contributor, 0.0f);
-		out_color[pix] = Crg.x + T * bg[0];
-		out_color[HW + pix] = Crg.y + T * bg[1];
-		out_color[2 * HW + pix] = C2 + T * bg[2];
-		out_refl[pix] = NzR.y;
-		out_others[0 * HW + pix] = DM.x;
-		out_others[1 * HW + pix] = 1 - T;
-		out_others[2 * HW + pix] = Nxy.x;
-		out_others[3 * HW + pix] = Nxy.y;
-		out_others[4 * HW + pix] = NzR.x;
-		out_others[5 * HW + pix] = median_depth;
-		out_others[6 * HW + pix] = distortion;
-		out_others[7 * HW + pix] = mask;
+		n_contrib[HW + p] = (uint32_t)fmaxf(st.median_contributor, 0.0f);
+		out_color[p] = st.Crg.x + T * bg[0];
+		out_color[HW + p] = st.Crg.y + T * bg[1];
+		out_color[2 * HW + p] = st.C2 + T * bg[2];
+		out_refl[p] = st.NzR.y;
+		out_others[0 * HW + p] = st.DM.x;
+		out_others[1 * HW + p] = 1 - T;
+		out_others[2 * HW + p] = st.Nxy.x;
+		out_others[3 * HW + p] = st.Nxy.y;
+		out_others[4 * HW + p] = st.NzR.x;
+		out_others[5 * HW + p] = st.median_depth;
+		out_others[6 * HW + p] = st.distortion;
+		out_others[7 * HW + p] = st.maskacc > 0.f ? 1.0f : 0.f;
 	}
 }
 
