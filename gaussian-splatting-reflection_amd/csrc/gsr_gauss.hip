@@ -88,6 +88,11 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	// SH rows of the wave's 64 Gaussians through LDS (coalesced; see stage_sh_rows) when the full 16-coefficient rows are needed
+	__shared__ float4 s_sh[4 * GSR_SH_LDS_F4_PER_WAVE];
+	float4* sh_wave = s_sh + (threadIdx.x >> 6) * GSR_SH_LDS_F4_PER_WAVE;
+	const bool sh_staged = colors_precomp == nullptr && M == 16 && D == 3;
+	if (sh_staged && (idx & ~63) < P) stage_sh_rows(shs, idx & ~63, P, sh_wave);
 	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
@@ -145,7 +150,8 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 		const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
 		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 		ShRow s;
-		load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+		if (sh_staged) load_sh_staged(sh_wave, s);
+		else load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 		const F3 c = sh_eval(D, s, dx / len, dy / len, dz / len);
 		g.clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
 		cr = fmaxf(c.x, 0.0f); cg = fmaxf(c.y, 0.0f); cb = fmaxf(c.z, 0.0f);
@@ -180,8 +186,10 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 // Per (pixel, Gaussian) falloff shared VERBATIM by the forward and backward tile kernels: the backward
 // recovers T by dividing by (1 - alpha), so alpha must be the same bits in both.  Explicit fmaf + no
 // further contraction makes the instruction sequence independent of the surrounding code.
-__device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, float pixx, float pixy, float& dx, float& dy, float& G,
-                                           float& alpha) {
+// Returns the lanes whose pair passes the reference's two tests (power > 0, alpha < 1/255: DGR forward.cu:357-366) as a
+// lane mask (see gsr_internal.hpp: explicit masks instead of bools keep hipcc from materialising ballots in VGPRs).
+__device__ __forceinline__ lmask gauss_pair(float4 r0, float conz, float opac, float pixx, float pixy, float& dx, float& dy, float& G,
+                                            float& alpha) {
 #pragma clang fp contract(off)
 	dx = r0.x - pixx;
 	dy = r0.y - pixy;
@@ -190,7 +198,7 @@ __device__ __forceinline__ bool gauss_pair(float4 r0, float conz, float opac, fl
 	// straight-line (no early return): G and alpha are defined in every lane, the callers zero them where the pair is rejected
 	G = __expf(power);
 	alpha = fminf(0.99f, opac * G);
-	return !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+	return LMASK(!(power > 0.0f)) & LMASK(!(alpha < 1.0f / 255.0f));
 }
 
 // renderCUDA forward (DGR forward.cu:274-411), wave-per-quadrant form (see surfel_render_fwd_wave_kernel in
@@ -225,13 +233,13 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	__shared__ uint32_t s_hid[G_WBATCH];
 	__shared__ uint32_t s_hj[G_WBATCH];
 
-	bool done = !inside;
+	lmask done = ~LMASK(px < W) | ~LMASK(py < H);   // lanes outside the image never blend
 	float T = 1.0f;
 	uint32_t last_contributor = 0;
 	float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, RS = 0, ID = 0;
 
 	for (int base = 0; base < count; base += G_WBATCH) {
-		if (__ballot(!done) == 0ull) break;
+		if (done == ~0ull) break;
 		const int nb = min(G_WBATCH, count - base);
 		bool hit = lane < nb;
 		uint32_t id = 0;
@@ -263,25 +271,24 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			const uint32_t contributor = (uint32_t)(base + (int)__builtin_amdgcn_readlane(hj, k) + 1);
 			// straight-line for all 64 lanes: a rejected pair blends with weight 0 (see surfel_render_fwd_wave_kernel)
 			float dx, dy, G, alpha;
-			const bool pair_ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, G, alpha);
+			const lmask live = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, G, alpha) & ~done;
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
 			__builtin_amdgcn_sched_barrier(0);
 			const float test_T = T * (1 - alpha);
-			const bool live = !done && pair_ok;
-			const bool sat = live && test_T < 0.0001f;
-			const bool ok = live && !sat;
-			done = done || sat;
-			if (__ballot(ok) != 0ull) {
-				const float w = ok ? alpha * T : 0.f;
+			const lmask sat = LMASK(test_T < 0.0001f) & live;   // saturated: the pair is dropped and the pixel retires
+			const lmask ok = live & ~sat;
+			done |= sat;
+			if (ok != 0ull) {
+				const float w = selm0(ok, alpha * T);
 				C0 = fmaf(R.r1.z, w, C0); C1 = fmaf(R.r1.w, w, C1); C2 = fmaf(R.r2.x, w, C2);
 				N0 = fmaf(R.r2.y, w, N0); N1 = fmaf(R.r2.z, w, N1); N2 = fmaf(R.r2.w, w, N2);
 				RS = fmaf(R.r3.x, w, RS);
 				if (INVDEPTH) ID = fmaf(R.r3.y, w, ID);
-				T = ok ? test_T : T;
-				last_contributor = ok ? contributor : last_contributor;
+				T = selm(ok, test_T, T);
+				last_contributor = selmu(ok, contributor, last_contributor);
 			}
-			return __ballot(sat) != 0ull && __ballot(!done) == 0ull;
+			return done == ~0ull;
 		};
 		Rec A = fetch(0), B = A;
 		for (int k = 0; k < nh; k += 2) {
@@ -337,7 +344,9 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	__shared__ uint32_t s_hid[G_WBATCH];
 	__shared__ uint32_t s_hj[G_WBATCH];
 
-	const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;   // row_reduce_groups lane predicates
+	const lmask inside_m = LMASK(px < W) & LMASK(py < H);
+	// where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register (row_reduce_slot)
+	const uint32_t slab_lane = (uint32_t)(lane >> 4) * G_ACC_F + (uint32_t)row_reduce_slot(lane);
 	const float T_final = inside ? final_Ts[pix] : 0.f;
 	float T = T_final;
 	const int last_contributor = inside ? (int)n_contrib[pix] : 0;
@@ -393,16 +402,16 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
 			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
 			float dx, dy, Gp, alpha_p;
-			const bool pair_ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, Gp, alpha_p);   // all lanes: fields must be defined
-			const bool ok = inside && contributor < last_contributor && pair_ok;
+			const lmask ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, Gp, alpha_p) & LMASK(contributor < last_contributor) & inside_m;
 			__builtin_amdgcn_sched_barrier(0);
 			prefetch_next();
 			__builtin_amdgcn_sched_barrier(0);
-			if (__ballot(ok) == 0ull) return;
+			if (ok == 0ull) return;
 			// Straight-line for all 64 lanes: a rejected pair runs with alpha = 0 (the identity of the recurrences) and
-			// G = 0, and has its root gradients zeroed, so every v[] comes out 0 without exec-mask regions.
+			// G = 0 (exp of a positive power may be inf), and has its root gradients zeroed, so every v[] comes out 0 without
+			// exec-mask regions.
 			float v[G_ACC_F];
-			const float alpha = ok ? alpha_p : 0.f, G = ok ? Gp : 0.f;
+			const float alpha = selm0(ok, alpha_p), G = selm0(ok, Gp);
 			const float inv_1ma = div_nr(1.0f, 1.f - alpha);
 			T *= inv_1ma;
 			const float w = alpha * T;
@@ -413,8 +422,8 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			A2 = last_alpha * D2p + (1.f - last_alpha) * A2;
 			D1p = D1; D2p = D2; last_alpha = alpha;
 			const float bgterm = -T_final * inv_1ma * bg_dot_dpixel;
-			const float dL_dalpha = ok ? (D1 - A1) * T + bgterm : 0.f;
-			const float dL_dalpha_means2d = ok ? (D2 - A2) * T + bgterm : 0.f;
+			const float dL_dalpha = selm0(ok, (D1 - A1) * T + bgterm);
+			const float dL_dalpha_means2d = selm0(ok, (D2 - A2) * T + bgterm);
 			v[GA_COLOR + 0] = w * dp0;
 			v[GA_COLOR + 1] = w * dp1;
 			v[GA_COLOR + 2] = w * dp2;
@@ -439,14 +448,12 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			v[GA_OPAC] = G * dL_dalpha;
 			// 16 values -> 4 registers of row totals (exchange-type DPP, see row_reduce_groups); the four 16-lane rows park
 			// theirs in separate slab rows and the flush adds them (as in surfel_render_bwd_wave_kernel)
+			// (the four lanes of a quad hold the same totals and store them to the same address: cheaper than masking three off)
 			float z[4];
-			row_reduce_groups<4>(v, z, up8, up4);
-			quad_sum4(z);
-			if ((lane & 3) == 0) {
-				float* slab = s_slab + (((k & (G_SUB - 1)) * 4 + (lane >> 4)) * G_ACC_F) + row_reduce_slot(lane);
+			row_reduce16(v, z);
+			float* slab = s_slab + (k & (G_SUB - 1)) * 4 * G_ACC_F + slab_lane;
 #pragma unroll
-				for (int g = 0; g < 4; g++) slab[4 * g] = z[g];
-			}
+			for (int g = 0; g < 4; g++) slab[4 * g] = z[g];
 			touched |= 1ull << k;
 		};
 		auto flush = [&](int k_last) {

@@ -189,6 +189,41 @@ __device__ __forceinline__ void row_reduce_groups(const float* v, float* z, bool
 		             : "=&v"(z[g]) : "v"(p[g]), "v"(q[g]));
 	}
 }
+// The same for the surfel backward's 20 values in as few issue slots as the hazards allow: the level-1 adds of all five
+// groups go into two asm blocks and the level-2 + quad adds into one, ordered so that no DPP reads a register written
+// less than three instructions earlier; only the block heads need an s_nop (the compiler's hazard recogniser does not look
+// inside asm and the preceding instruction may have written an input).  40 DPP adds + 3 s_nop instead of 40 + 11.
+#define GSR_L1(CTRL, d, a, b) GSR_DPPB(CTRL, "0x3", d, a) GSR_DPPB(CTRL, "0xc", d, b)
+__device__ __forceinline__ void row_reduce20(const float* v, float* z) {
+	float p0, q0, p1, q1, p2, q2, p3, q3, p4, q4;
+	asm volatile("s_nop 1\n\t" GSR_L1("row_mirror", 0, 6, 7) GSR_L1("row_mirror", 1, 8, 9) GSR_L1("row_mirror", 2, 10, 11)
+	             GSR_L1("row_mirror", 3, 12, 13) GSR_L1("row_mirror", 4, 14, 15) GSR_L1("row_mirror", 5, 16, 17)
+	             : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2)
+	             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]));
+	asm volatile("s_nop 1\n\t" GSR_L1("row_mirror", 0, 4, 5) GSR_L1("row_mirror", 1, 6, 7) GSR_L1("row_mirror", 2, 8, 9) GSR_L1("row_mirror", 3, 10, 11)
+	             : "=&v"(p3), "=&v"(q3), "=&v"(p4), "=&v"(q4)
+	             : "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]), "v"(v[19]));
+#define GSR_L2(d, a, b) GSR_DPPB("row_half_mirror", "0x5", d, a) GSR_DPPB("row_half_mirror", "0xa", d, b)
+#define GSR_QA(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3) GSR_Q1(CTRL, 4)
+	asm volatile("s_nop 1\n\t" GSR_L2(0, 5, 6) GSR_L2(1, 7, 8) GSR_L2(2, 9, 10) GSR_L2(3, 11, 12) GSR_L2(4, 13, 14)
+	             GSR_QA("quad_perm:[2,3,0,1]") GSR_QA("quad_perm:[1,0,3,2]")
+	             : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3]), "=&v"(z[4])
+	             : "v"(p0), "v"(q0), "v"(p1), "v"(q1), "v"(p2), "v"(q2), "v"(p3), "v"(q3), "v"(p4), "v"(q4));
+}
+// 16 values (variant G's backward): 32 DPP adds + 2 s_nop.
+__device__ __forceinline__ void row_reduce16(const float* v, float* z) {
+	float p0, q0, p1, q1, p2, q2, p3, q3;
+	asm volatile("s_nop 1\n\t" GSR_L1("row_mirror", 0, 8, 9) GSR_L1("row_mirror", 1, 10, 11) GSR_L1("row_mirror", 2, 12, 13) GSR_L1("row_mirror", 3, 14, 15)
+	             GSR_L1("row_mirror", 4, 16, 17) GSR_L1("row_mirror", 5, 18, 19) GSR_L1("row_mirror", 6, 20, 21) GSR_L1("row_mirror", 7, 22, 23)
+	             : "=&v"(p0), "=&v"(q0), "=&v"(p1), "=&v"(q1), "=&v"(p2), "=&v"(q2), "=&v"(p3), "=&v"(q3)
+	             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+	               "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+#define GSR_QB(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3)
+	asm volatile("s_nop 1\n\t" GSR_L2(0, 4, 5) GSR_L2(1, 6, 7) GSR_L2(2, 8, 9) GSR_L2(3, 10, 11)
+	             GSR_QB("quad_perm:[2,3,0,1]") GSR_QB("quad_perm:[1,0,3,2]")
+	             : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
+	             : "v"(p0), "v"(q0), "v"(p1), "v"(q1), "v"(p2), "v"(q2), "v"(p3), "v"(q3));
+}
 // levels 3 and 4 (interleaved so that no DPP reads a register written < 2 instructions before)
 __device__ __forceinline__ void quad_sum5(float* z) {
 #define GSR_Q5(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3) GSR_Q1(CTRL, 4)

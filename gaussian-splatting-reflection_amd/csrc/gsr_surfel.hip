@@ -149,6 +149,11 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	// SH rows of the wave's 64 surfels through LDS (coalesced; see stage_sh_rows) when the full 16-coefficient rows are needed
+	__shared__ float4 s_sh[4 * GSR_SH_LDS_F4_PER_WAVE];
+	float4* sh_wave = s_sh + (threadIdx.x >> 6) * GSR_SH_LDS_F4_PER_WAVE;
+	const bool sh_staged = colors_precomp == nullptr && M == 16 && D == 3;
+	if (sh_staged && (idx & ~63) < P) stage_sh_rows(shs, idx & ~63, P, sh_wave);
 	if (idx >= P) return;
 	radii[idx] = 0;
 	gaussian_weights[idx] = 0.f;   // the tile kernel merges per-wave maxima into it with atomicMax
@@ -201,7 +206,8 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 		const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
 		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 		ShRow s;
-		load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+		if (sh_staged) load_sh_staged(sh_wave, s);
+		else load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 		const F3 c = sh_eval(D, s, dx / len, dy / len, dz / len);
 		g.clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
 		cr = fmaxf(c.x, 0.0f); cg = fmaxf(c.y, 0.0f); cb = fmaxf(c.z, 0.0f);
@@ -551,7 +557,7 @@ struct SurfelBwdPix {
 	float T, T_final, last_dL_dT, bg_dot_dpixel;
 	int last_contributor, median_contributor;
 	v2f dp01, dn01, dnzr;          // upstream gradients paired like the record: (r, g), (n.x, n.y), (n.z, refl)
-	v2f pixm;                      // (pix.x, -pix.y)
+	v2f pixs;                      // (-pix.y, pix.x)
 	float dp2, dL_ddepth, dL_daccum, dL_dmedian_depth;
 	float FD2r, FAr, FDr;          // final_D2, final_A, final_D times dL_dreg
 	float A, Dprev, last_alpha;    // blended <attributes, upstream grads> behind this pixel's current position
@@ -584,22 +590,60 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 	s.A = s.Dprev = s.last_alpha = 0.f;
 	s.bg_dot_dpixel = bg[0] * s.dp01.x + bg[1] * s.dp01.y + bg[2] * s.dp2;
 }
-// One (pixel, surfel) pair of the back-to-front recursion (DSR backward.cu:338-467): advances the per-pixel state and
-// writes the 19 gradient contributions (slots SA_*) into v.  Straight-line for all 64 lanes:
-//   * a lane whose pair does not contribute (`ok` false) runs with alpha = 0, which is the identity of every
-//     recurrence below (T/(1-0), blend weights 0), and has its two root gradients zeroed, so all of v comes out 0
-//     without exec-mask regions or a zero-fill of v;
+// One (wave, surfel) pair of the back-to-front recursion (DSR backward.cu:292-467): ray-splat intersection with the
+// backward's `unstable` threshold (1e-6; the forward uses 1e-4 — a quirk of the reference, reproduced), then the per-pixel
+// state advance and the 19 gradient contributions (slots SA_*) into v.  Returns the lanes that contribute (0: nothing was
+// written).  Straight-line for all 64 lanes, predicates as lane masks (see surfel_fwd_pair):
+//   * a lane whose pair does not contribute runs with alpha = 0, which is the identity of every recurrence below
+//     (T/(1-0), blend weights 0), and has its two root gradients zeroed, so all of v comes out 0 without exec-mask regions
+//     or a zero-fill of v; depth and s are sanitised there too (they multiply those zeros and feed the recurrences);
 //   * the reference keeps, per output channel x, accum_rec_x = last_alpha*last_x + (1-last_alpha)*accum_rec_x and adds
 //     (x - accum_rec_x)*dL_dx to dL_dalpha; only the dot product over channels is ever used, and the recurrence is
 //     linear, so ONE scalar recurrence A over D = <attributes, upstream grads> replaces the nine (same value up
 //     to summation order);
-//   * 1/(1-alpha), 1/depth and 1/p.z are formed once (Newton-refined v_rcp) and multiplied through.
-__device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPair& o, bool ok, const SurfelRec& R, int contributor, float* v) {
-	const float alpha = ok ? o.alpha : 0.f;
-	const float c_d = ok ? o.depth : 1.0f;
-	// a rejected pair may carry inf/NaN here (s overflows when the ray grazes the splat plane); 0 * that must stay 0
-	const float G = ok ? o.G : 0.f;
-	const v2f sxy = mk2(ok ? o.s.x : 0.f, ok ? o.s.y : 0.f);
+//   * 1/(1-alpha), 1/depth and 1/p.z are formed once (Newton-refined v_rcp) and multiplied through;
+//   * the cross products dL_dk = l x dL_dp, dL_dl = dL_dp x k are formed on the pairs X = (k.x, l.x), Y, Z in their
+//     natural order, which yields the results SWAPPED, (-nl, nk) per component; the consumers index accordingly (no
+//     register shuffles).
+__device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRec& R, const v2f pix, int contributor, lmask inside_m, float* v) {
+	v2f X, Y, Z, d;
+	float sx, sy, rho3d, rho2d, depth, inv_pz;
+	{
+#pragma clang fp contract(off)
+		const v2f Tw = R.Twxy();
+		X = pix * Tw.x - R.TuvX();
+		Y = pix * Tw.y - R.TuvY();
+		Z = pix * R.Twz() - R.TuvZ();
+		const v2f a = Y * Z.yx;
+		const v2f b = Z * X.yx;
+		const v2f c = X * Y.yx;
+		const float ppx = a.x - a.y, ppy = b.x - b.y, pz = c.x - c.y;
+		const lmask unstable = LMASK(fabsf(pz) < 1e-6f);
+		if (__builtin_expect(unstable == 0ull, 1)) {
+			inv_pz = div_nr(1.0f, pz);   // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale)
+			sx = ppx * inv_pz; sy = ppy * inv_pz;
+			rho3d = sx * sx + sy * sy;
+		} else {
+			inv_pz = div_nr(1.0f, selm(unstable, 1.0f, pz));
+			sx = selm(unstable, 0.f, ppx * inv_pz); sy = selm(unstable, 0.f, ppy * inv_pz);
+			rho3d = selm(unstable, 1e8f, sx * sx + sy * sy);
+		}
+		d = R.xy() - pix;
+		const v2f d2 = d * d;
+		rho2d = S_FILTER_INV_SQ * (d2.x + d2.y);
+		const v2f st2 = mk2(sx, sy) * Tw;
+		depth = (st2.x + st2.y) + R.Twz();
+	}
+	const float power = -0.5f * min_raw(rho3d, rho2d);
+	const float G = exp_neg(power);   // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by this backward
+	const float alpha_raw = fminf(0.99f, R.opac() * G);
+	const lmask ok = LMASK(!(depth < S_NEAR)) & LMASK(!(alpha_raw < 1.0f / 255.0f)) & LMASK(contributor < s.last_contributor) & inside_m;
+	if (ok == 0ull) return 0ull;
+	const float alpha = selm0(ok, alpha_raw);
+	const float c_d = selm(ok, depth, 1.0f);
+	// a rejected pair may carry inf/NaN in s (it overflows when the ray grazes the splat plane); 0 * that must stay 0.  G needs
+	// no such care: v_min drops a NaN rho3d, so it is always in [0, 1].
+	const v2f sxy = mk2(selm0(ok, sx), selm0(ok, sy));
 	const float inv_1ma = div_nr(1.0f, 1.f - alpha);
 	s.T *= inv_1ma;
 	const float T = s.T;
@@ -634,38 +678,34 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 	dL_dz += (contributor == s.median_contributor - 1) ? s.dL_dmedian_depth : 0.f;
 	dL_dalpha *= T;
 	dL_dalpha -= s.T_final * inv_1ma * s.bg_dot_dpixel;
-	dL_dalpha = ok ? dL_dalpha : 0.f;
-	dL_dz = ok ? dL_dz : 0.f;
+	dL_dalpha = selm0(ok, dL_dalpha);
+	dL_dz = selm0(ok, dL_dz);
 	const float nG = -G * (R.opac() * dL_dalpha);   // dL_dG * -G
-	const bool use3d = o.rho3d <= o.rho2d;
+	const lmask use3d = LMASK(rho3d <= rho2d);
 	// dL_ds = nG * s + dL_dz * Tw.xy on the ray-splat branch, 0 on the low-pass branch
-	v2f dL_ds = __builtin_elementwise_fma(mk2(nG, nG), sxy, mk2(dL_dz, dL_dz) * R.Twxy());
-	dL_ds = mk2(use3d ? dL_ds.x : 0.f, use3d ? dL_ds.y : 0.f);
-	const v2f dp = dL_ds * o.inv_pz;                       // dL_dp.xy
+	const v2f dL_ds = __builtin_elementwise_fma(mk2(nG, nG), sxy, mk2(dL_dz, dL_dz) * R.Twxy());
+	const v2f dp = mk2(selm0(use3d, dL_ds.x), selm0(use3d, dL_ds.y)) * inv_pz;   // dL_dp.xy
 	const v2f dps = dp * sxy;
 	const float dpz = -(dps.x + dps.y);
-	// dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k).  With X = (k.x, l.x) etc. the pairs
-	//   N1 = X~ ... : (nk.x, -nl.x) = Z.yx * dp.y - Y.yx * dp.z,  (nk.y, -nl.y) = X.yx * dp.z - Z.yx * dp.x,
-	//   (nk.z, -nl.z) = Y.yx * dp.x - X.yx * dp.y      with nk = -dL_dk, nl = -dL_dl (what the T rows receive)
-	// cost two packed instructions each.  The accumulator therefore holds -nl in slots SA_T+3..5; the per-Gaussian
-	// backward flips the sign when it reads them.
-	const v2f Xs = o.X.yx, Ys = o.Y.yx, Zs = o.Z.yx;
+	// With X = (k.x, l.x) etc.:  Z * dp.y - Y * dp.z = (k.z dp.y - k.y dp.z, l.z dp.y - l.y dp.z) = (-nl.x, nk.x) where
+	// nk = -dL_dk = -(l x dp) and nl = -dL_dl = -(dp x k) are what the Tu / Tv rows receive.  The accumulator holds -nl in
+	// slots SA_T+3..5; the per-Gaussian backward flips the sign when it reads them.
 	const v2f dpx2 = mk2(dp.x, dp.x), dpy2 = mk2(dp.y, dp.y), dpz2 = mk2(dpz, dpz);
-	const v2f N1 = __builtin_elementwise_fma(Zs, dpy2, -(Ys * dpz2));
-	const v2f N2 = __builtin_elementwise_fma(Xs, dpz2, -(Zs * dpx2));
-	const v2f N3 = __builtin_elementwise_fma(Ys, dpx2, -(Xs * dpy2));
-	v[SA_T + 0] = N1.x; v[SA_T + 1] = N2.x; v[SA_T + 2] = N3.x;
-	v[SA_T + 3] = N1.y; v[SA_T + 4] = N2.y; v[SA_T + 5] = N3.y;       // = -nl
-	// third row: dL_dz * (s, 1) - (pix.x * nk + pix.y * nl) = dL_dz * (s, 1) - (pixm . N), pixm = (pix.x, -pix.y)
-	const v2f t1 = N1 * s.pixm, t2 = N2 * s.pixm, t3 = N3 * s.pixm;
-	v[SA_T + 6] = dL_dz * sxy.x - (t1.x + t1.y);
-	v[SA_T + 7] = dL_dz * sxy.y - (t2.x + t2.y);
-	v[SA_T + 8] = dL_dz - (t3.x + t3.y);
-	const float g2 = use3d ? 0.f : nG * S_FILTER_INV_SQ;   // low-pass branch: gradient to the 2D centre only
-	const v2f gm = o.d * g2;
+	const v2f N1 = __builtin_elementwise_fma(Z, dpy2, -(Y * dpz2));      // (-nl.x, nk.x)
+	const v2f N2 = __builtin_elementwise_fma(X, dpz2, -(Z * dpx2));      // (-nl.y, nk.y)
+	const v2f N3 = __builtin_elementwise_fma(Y, dpx2, -(X * dpy2));      // (-nl.z, nk.z)
+	v[SA_T + 0] = N1.y; v[SA_T + 1] = N2.y; v[SA_T + 2] = N3.y;
+	v[SA_T + 3] = N1.x; v[SA_T + 4] = N2.x; v[SA_T + 5] = N3.x;       // = -nl
+	// third row: dL_dz * (s, 1) - (pix.x * nk + pix.y * nl) = dL_dz * (s, 1) - (N . pixs), pixs = (-pix.y, pix.x)
+	const v2f t1 = N1 * s.pixs, t2 = N2 * s.pixs, t3 = N3 * s.pixs;
+	v[SA_T + 6] = dL_dz * sxy.x - (t1.y + t1.x);
+	v[SA_T + 7] = dL_dz * sxy.y - (t2.y + t2.x);
+	v[SA_T + 8] = dL_dz - (t3.y + t3.x);
+	const v2f gm = d * selm(use3d, 0.f, nG * S_FILTER_INV_SQ);   // low-pass branch: gradient to the 2D centre only
 	v[SA_MEAN2D + 0] = gm.x;
 	v[SA_MEAN2D + 1] = gm.y;
 	v[SA_OPAC] = G * dL_dalpha;
+	return ok;
 }
 
 // Wave-per-quadrant backward.  One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a tile and
@@ -675,7 +715,7 @@ __device__ __forceinline__ void surfel_bwd_pair(SurfelBwdPix& s, const SurfelPai
 //   2. the wave differentiates the survivors one at a time; the record of the current one is wave-uniform and arrives
 //      through the scalar memory path into SGPRs (two buffers ping-pong), nothing is staged in LDS;
 //   3. per contributing surfel the 19 gradient values are reduced over each 16-lane row with exchange-type DPP
-//      (row_reduce_groups) and parked in the slab row of (hit, row);
+//      (row_reduce20) and parked in the slab row of (hit, row);
 //   4. every S_SUB hits the wave adds the four row totals and flushes them as 80 contiguous bytes of float atomics per
 //      surfel into acc[P][20].
 // No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
@@ -695,7 +735,8 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	if (bx0 >= W || by0 >= H) return;
 	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
 	const bool inside = px < W && py < H;
-	const float pixx = (float)px, pixy = (float)py;
+	const lmask inside_m = LMASK(px < W) & LMASK(py < H);
+	const v2f pixv = mk2((float)px, (float)py);
 	const uint2 range = ranges[tile];
 	const int count = (int)(range.y - range.x);
 	const size_t HW = (size_t)H * W;
@@ -704,17 +745,18 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 
 	__shared__ float4 s_slab[S_SUB * 4 * (S_ACC_F / 4)];   // [hit in sub-batch][16-lane row][20 floats]
 	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
-	__shared__ uint32_t s_hj[S_WBATCH];    // its position inside the batch
+	__shared__ uint32_t s_hc[S_WBATCH];    // its contributor number (0-based position in the tile's list)
 
-	const bool up8 = (lane & 8) != 0, up4 = (lane & 4) != 0;   // upper half of the row / of the 8-lane half (row_reduce4)
 	SurfelBwdPix st;
 	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
-	st.pixm = mk2(pixx, -pixy);
+	st.pixs = mk2(-pixv.y, pixv.x);
 	// entries at or beyond the furthest last-contributor of the 64 pixels can be dropped for the whole wave
 	int wave_last = st.last_contributor;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
 	if (wave_last == 0) return;
+	// where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register (row_reduce_slot)
+	const uint32_t slab_lane = (uint32_t)(lane >> 4) * S_ACC_F + (uint32_t)row_reduce_slot(lane);
 
 	// skip the batches that lie entirely beyond wave_last (list is walked back to front)
 	const int first = max(0, count - wave_last);
@@ -732,52 +774,39 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
-		// ---- 2. compact: lane k ends up holding the id / batch position of the k-th surviving entry
+		// ---- 2. compact: lane k ends up holding the id / contributor number of the k-th surviving entry
 		if (hit) {
 			const int k = __popcll(mm & ((1ull << lane) - 1ull));
 			s_hid[k] = id;
-			s_hj[k] = (uint32_t)lane;
+			s_hc[k] = (uint32_t)(count - 1 - (base + lane));
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
-		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
-		// ---- 3. blend the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
+		const uint32_t hc = lane < nh ? s_hc[lane] : 0u;
+		// ---- 3. differentiate the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
 		// (v_readlane) and the 80-byte record comes in through the SCALAR memory path (s_load_dwordx4) into SGPRs:
 		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
-		// current one is being differentiated.
+		// current one is being differentiated (two SGPR buffers ping-pong; with a single rotating buffer the compiler
+		// copies the loaded SGPRs and waits for the load immediately).
 		unsigned long long touched = 0ull;
-		// Ping-pong between two SGPR record buffers (A, B): the s_load of the next record is issued right after the
-		// ray-splat evaluation of the current one and is only waited for one full gradient section later.  (With a
-		// single rotating buffer the compiler copies the loaded SGPRs and waits for the load immediately.)
 		using Rec = SurfelRec;
 		auto fetch = [&](int k) -> Rec {
 			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
 		};
-		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
-			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
-			SurfelPair o;
-			// evaluated for all 64 lanes (no short-circuit): the straight-line gradient code below multiplies every field of
-			// `o` by zero in rejected lanes, so the fields must be defined (finite) there too
-			const bool pair_ok = surfel_pair<false>(R, pixx, pixy, o);
-			const bool ok = inside && contributor < st.last_contributor && pair_ok;
-			__builtin_amdgcn_sched_barrier(0);
-			prefetch_next();
-			__builtin_amdgcn_sched_barrier(0);
-			if (__ballot(ok) == 0ull) return;
+		auto differentiate = [&](int k, const Rec& R) {
+			const int contributor = (int)__builtin_amdgcn_readlane(hc, k);
 			float v[S_ACC_F];
 			v[S_ACC_F - 1] = 0.f;
-			surfel_bwd_pair(st, o, ok, R, contributor, v);
-			// 20 values -> 5 registers of row totals (exchange-type DPP only); quad q of row r parks value slot(q) of each
-			// register in the slab row of (hit, r).  The four rows are added up by the flush.
+			if (surfel_bwd_pair(st, R, pixv, contributor, inside_m, v) == 0ull) return;
+			// 20 values -> 5 registers of row totals (exchange-type DPP only); every lane of quad q of row r holds value slot(q)
+			// of each register and parks it in the slab row of (hit, r) — the four lanes of a quad store the same value to the
+			// same address, which is cheaper than masking three of them off.  The four rows are added up by the flush.
 			float z[5];
-			row_reduce_groups<5>(v, z, up8, up4);
-			quad_sum5(z);
-			if ((lane & 3) == 0) {
-				float* slab = reinterpret_cast<float*>(s_slab) + (((k & (S_SUB - 1)) * 4 + (lane >> 4)) * S_ACC_F) + row_reduce_slot(lane);
+			row_reduce20(v, z);
+			float* slab = reinterpret_cast<float*>(s_slab) + (k & (S_SUB - 1)) * 4 * S_ACC_F + slab_lane;
 #pragma unroll
-				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
-			}
+			for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
 			touched |= 1ull << k;
 		};
 		// ---- 4. flush, every S_SUB hits: lane -> (hit, float d); the four row totals are added here and leave as 80
@@ -789,10 +818,10 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 				const float* slab = reinterpret_cast<const float*>(s_slab);
 				const int n = (k_last - k0 + 1) * S_ACC_F;
 				for (int item = lane; item < n; item += 64) {
-					const int kk = item / S_ACC_F, d = item - kk * S_ACC_F;
-					if (d < S_ACC_F - 1 && ((touched >> (k0 + kk)) & 1ull)) {
-						const float* row = slab + kk * 4 * S_ACC_F + d;
-						atomicAdd(acc + (size_t)s_hid[k0 + kk] * S_ACC_F + d, (row[0] + row[S_ACC_F]) + (row[2 * S_ACC_F] + row[3 * S_ACC_F]));
+					const int kk = item / S_ACC_F, dd = item - kk * S_ACC_F;
+					if (dd < S_ACC_F - 1 && ((touched >> (k0 + kk)) & 1ull)) {
+						const float* row = slab + kk * 4 * S_ACC_F + dd;
+						atomicAdd(acc + (size_t)s_hid[k0 + kk] * S_ACC_F + dd, (row[0] + row[S_ACC_F]) + (row[2 * S_ACC_F] + row[3 * S_ACC_F]));
 					}
 				}
 			}
@@ -800,9 +829,11 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 		};
 		Rec A = fetch(0), B = A;
 		for (int k = 0; k < nh; k += 2) {
-			differentiate(k, A, [&]() { if (k + 1 < nh) B = fetch(k + 1); });
+			if (k + 1 < nh) B = fetch(k + 1);
+			differentiate(k, A);
 			if (k + 1 >= nh) { flush(k); break; }
-			differentiate(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); });
+			if (k + 2 < nh) A = fetch(k + 2);
+			differentiate(k + 1, B);
 			if (((k + 1) & (S_SUB - 1)) == S_SUB - 1 || k + 2 >= nh) flush(k + 1);
 		}
 	}
