@@ -1,19 +1,24 @@
 #!/usr/bin/env python
-"""Headline benchmark: one "step" = forward + backward of the hot path for one 1080p view of 1e6
-Gaussians (BASELINE config C3): surfel rasterizer (variant S, the one gaussian_renderer calls) +
-fused deferred reflection / cubemap lookup, then their backward with synthetic upstream gradients.
+"""Headline benchmark: one "step" = forward + backward of the hot path for the views of one training batch of the
+1e6-Gaussian 1080p scene (surfel rasterizer — the one gaussian_renderer calls — + fused deferred reflection / cubemap lookup,
+then their backward with synthetic upstream gradients).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--views V]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own view of the same
-1e6-Gaussian scene (weak scaling: per-GPU work fixed) and the per-Gaussian + cubemap gradients are summed
-with ONE RCCL all-reduce over a flat pre-packed buffer.  value = views/s over all ranks.
+N = 1 (default): BASELINE config C3 — ONE view per step, no collective.
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE config C4 — a batch of V = 8 views per step sharded over
+the ranks (rank r renders views r, r+N, ...; 8/N views each), every rank ACCUMULATES its views' per-Gaussian + cubemap gradients
+on the device in one flat buffer (kernel `+=`, gradient sinks), then ONE RCCL all-reduce of that buffer INSIDE the step:
+the next step starts only when the reduced gradients are there, as a training step (Adam) needs them.  Total work per step is
+fixed (strong scaling).  value = views/s over all ranks.  `--views 8 --gpus 1` runs the same batch on one GPU.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (tile-render backward): algorithmic bytes / hipEvent-measured launch time
-  cpu_baseline  the CPU oracle (oracle/, "port") timed on this host on one full C3 step
-and, beside them, `full_train_step`: the same step + L1/SSIM loss + gradient all-reduce + fused Adam (secondary figure,
-never `value`; --no-full-step skips it).
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline         dominant kernel (tile-render backward): algorithmic bytes / hipEvent-measured launch time (bound: hbm), and
+                   bound2 = VALU issue (wave-instructions per launch from the committed PMC pass / launch time vs 1 per 2 cycles)
+  cpu_baseline     the CPU oracle (oracle/, "port") on this host: one full C3 step on all cores + a bounded single-thread sample
+  full_train_step  the same step + L1/SSIM loss + gradient all-reduce + fused Adam (secondary figure, never `value`)
+  c5               BASELINE config C5 (5e6 Gaussians, 3DGS rasterizer, anti-aliasing + inverse-depth backward) on this GPU
+  allreduce        (N > 1) payload, and the time of a loop that overlaps the all-reduce with the next step (labelled extra)
 """
 import argparse
 import json
@@ -31,11 +36,13 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def yaw_camera(S, W, H, deg):
-    """Base C3 camera (R = I, T = 0) rotated about the y axis by `deg` degrees: rank r looks r*3 degrees to the side."""
+    """Base C3 camera (R = I, T = 0) rotated about the y axis by `deg` degrees: view v looks 3 v degrees to the side."""
     a = math.radians(deg)
     c2w = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=np.float64)
     return S.make_camera(W, H, R=c2w, T=np.zeros(3))
@@ -55,7 +62,6 @@ class Scene:
         src["fail"] = torch.from_numpy(fail)
         self.p = {k: v.to(device).requires_grad_(True) for k, v in src.items()}
         self.grads = FlatGrads(self.p)
-        self.flat_grad = self.grads.flat
         self.mask = torch.from_numpy(sc["env_scope_mask"]).to(device)
         self.P = P
 
@@ -63,7 +69,7 @@ class Scene:
         """Drop parameters and the flat gradient buffer (the end-to-end leg re-creates them inside its own flat store)."""
         for p in self.p.values():
             p.grad = None
-        self.p, self.grads, self.flat_grad = {}, None, None
+        self.p, self.grads = {}, None
 
 
 class EnvMap:
@@ -71,20 +77,44 @@ class EnvMap:
         self.params = {"Cubemap_texture": tex, "Cubemap_failv": fail}
 
 
+class View:
+    """One camera of the batch with its own rasterizer instance (the gradient sink is per rasterizer)."""
+
+    def __init__(self, S, index, W, H, dev):
+        from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        cam = yaw_camera(S, W, H, 3.0 * index)
+        self.ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
+        self.HWK = (H, W, cam["K"])
+        settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                                 bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=self.ct["viewmatrix"],
+                                                 projmatrix=self.ct["projmatrix"], sh_degree=3, campos=self.ct["campos"], prefiltered=False,
+                                                 debug=False)
+        self.rasterizer = GaussianRasterizer(settings)
+
+
+def percentiles(ms):
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    if a.size == 0:
+        return None
+    q = lambda f: float(a[min(a.size - 1, int(round(f * (a.size - 1))))])
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(float(a[0]), 4), "max": round(float(a[-1]), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views", type=int, default=0, help="views per step over all ranks (default: 1 on one GPU = C3, 8 on several = C4)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mu", type=float, default=-4.75)
     ap.add_argument("--cubemap", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--trace-steps", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary end-to-end (loss + Adam) timing")
-    ap.add_argument("--serial-allreduce", action="store_true", help="N > 1: all-reduce inside every step instead of overlapping it with the next one")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 (5e6 Gaussians, variant G) object")
+    ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,79 +135,51 @@ def main():
 
     import gsr_synth as S
     import _gsr
-    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from gaussian_renderer import deferred_reflection
+    from gsr_dist import shard_views
 
     if os.environ.get("GSR_DEV"):
         _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))   # development ablations only (tests/ablate.py)
     P, W, H = args.gaussians, args.width, args.height
+    views_total = args.views if args.views > 0 else (8 if dist_on else 1)
+    my_views = shard_views(views_total, rank, world)
+    if not my_views:
+        raise SystemExit("bench: fewer views per step (%d) than ranks (%d)" % (views_total, world))
     scene = Scene(S, P, args.mu, args.cubemap, dev, seed=1003)
-    cam = yaw_camera(S, W, H, 3.0 * rank)
-    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
-    bg = torch.zeros(3, device=dev)
-    settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg,
-                                             scale_modifier=1.0, viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"], sh_degree=3,
-                                             campos=ct["campos"], prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(settings)
+    views = [View(S, v, W, H, dev) for v in my_views]
     env = EnvMap(scene.p["cubemap"], scene.p["fail"])
-    HWK = (H, W, cam["K"])
     g = S.make_upstream_grads(H, W, 1003)
     g_final = torch.from_numpy(g["dL_dcolor"]).to(dev)
     g_allmap = torch.from_numpy(g["dL_dplanes"]).to(dev)
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     info = {}
-    refl_sink = [None]    # gradient sink of the fused reflection op for the next forward (bound per call)
 
-    def forward():
-        base, radii, allmap, refl_map, gw = rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
-                                                       shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
-                                                       scales=scene.p["scales"], rotations=scene.p["rotations"],
-                                                       env_scope_mask=scene.mask)
-        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], HWK, ct["R"], ct["T"],
-                                                     grad_sink=refl_sink[0])
+    def render(view, refl_sink, accumulate):
+        ct = view.ct
+        base, radii, allmap, refl_map, gw = view.rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
+                                                            shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
+                                                            scales=scene.p["scales"], rotations=scene.p["rotations"],
+                                                            env_scope_mask=scene.mask)
+        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
+                                                     grad_sink=refl_sink, accumulate=accumulate)
         if base.grad_fn is not None:
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
 
-    # the backward kernels write their parameter gradients straight into a flat all-reduce buffer (gradient sinks).  With
-    # more than one rank there are two such buffers used alternately: the all-reduce of step k (RCCL, its own stream) runs
-    # while step k+1 renders and writes the other buffer; a buffer is reused only after its all-reduce has completed.
-    # Nothing consumes the reduced gradients in this leg, so the pipelining changes no result; the end-to-end leg below
-    # (optimizer step after every all-reduce) has the strict dependency and reports the unhidden cost.
-    overlap = dist_on and not args.serial_allreduce
-    scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
-    bufs = [scene.grads] + ([scene.grads.twin()] if overlap else [])
-    sinks = [(b.sink(), b.sink(names=("cubemap", "fail"))) for b in bufs]
-    pending = [None] * len(bufs)
-    overlap_failed = []
-    counter = [0]
+    # The backward kernels write their parameter gradients straight into the flat all-reduce buffer (gradient sinks): the first
+    # view of a step overwrites it, every further view of this rank adds to it on the device (accumulate mode) — no zero-fill,
+    # no autograd accumulation passes.  Then ONE all-reduce, inside the step.
+    def step_into(buf, reduce):
+        sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
+        for i, view in enumerate(views):
+            view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
+            means2D.grad = None
+            final, allmap = render(view, rsink, i > 0)
+            torch.autograd.backward([final, allmap], [g_final, g_allmap])
+        return reduce(buf)
 
     def step():
-        k = counter[0] % len(bufs)
-        counter[0] += 1
-        if pending[k] is not None:
-            pending[k].wait()              # the current stream waits for this buffer's previous all-reduce
-            pending[k] = None
-        rasterizer.set_grad_sink(sinks[k][0])
-        refl_sink[0] = sinks[k][1]              # every gradient is sunk: nothing left for autograd to zero or accumulate
-        means2D.grad = None
-        final, allmap = forward()
-        torch.autograd.backward([final, allmap], [g_final, g_allmap])
-        if overlap and not overlap_failed:
-            try:
-                pending[k] = bufs[k].all_reduce_async()
-            except Exception as ex:   # keep the run alive: fall back to the all-reduce inside every step
-                overlap_failed.append(repr(ex))
-                print("bench: asynchronous all-reduce failed (%r); continuing with the serial one" % (ex,), file=sys.stderr, flush=True)
-                bufs[k].all_reduce()
-        else:
-            bufs[k].all_reduce()
-
-    def drain():
-        for k, w in enumerate(pending):
-            if w is not None:
-                w.wait()
-                pending[k] = None
+        step_into(scene.grads, lambda b: b.all_reduce())
 
     def sync_all():
         if dist_on:
@@ -186,150 +188,132 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    drain()
     sync_all()
     _gsr.profile_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
-    drain()
+    marks[args.steps].record()
     sync_all()
     dt = time.perf_counter() - t0
     stages = _gsr.profile_collect()
     _gsr.profile_enable(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
-    # N > 1, for transparency: the same steps with the all-reduce inside every step (what a strictly sequential loop pays)
-    serial_ms = None
-    if overlap:
-        def serial_step():
-            rasterizer.set_grad_sink(sinks[0][0])
-            refl_sink[0] = sinks[0][1]
-            means2D.grad = None
-            final, allmap = forward()
-            torch.autograd.backward([final, allmap], [g_final, g_allmap])
-            bufs[0].all_reduce()
-        for _ in range(2):
-            serial_step()
-        sync_all()
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            serial_step()
-        sync_all()
-        tser = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
-        dist.all_reduce(tser, op=dist.ReduceOp.MAX)
-        serial_ms = float(tser.item()) / args.steps * 1e3
+    # N > 1, labelled extra: the same steps with the all-reduce of step k (RCCL, its own stream) overlapped with step k+1, which
+    # renders into a second buffer.  Nothing consumes the reduced gradients in that loop — a training step cannot do this
+    # (Adam needs them before the next forward) — so it is NOT the headline.
+    overlap_ms = None
+    if dist_on and not args.no_overlap_extra:
+        try:
+            bufs = [scene.grads, scene.grads.twin()]
+            pending = [None, None]
+
+            def overlapped(k):
+                if pending[k] is not None:
+                    pending[k].wait()
+                pending[k] = step_into(bufs[k], lambda b: b.all_reduce_async())
+            for i in range(2):
+                overlapped(i % 2)
+            sync_all()
+            ts = time.perf_counter()
+            for i in range(args.steps):
+                overlapped(i % 2)
+            for w in pending:
+                if w is not None:
+                    w.wait()
+            sync_all()
+            tov = torch.tensor([time.perf_counter() - ts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tov, op=dist.ReduceOp.MAX)
+            overlap_ms = float(tov.item()) / args.steps * 1e3
+            del bufs
+        except Exception as ex:     # keep the run alive: the extra is optional
+            print("bench: overlapped extra loop failed (%r); skipped" % (ex,), file=sys.stderr, flush=True)
 
     # forward-only render rate (render FPS @1080p), un-timed for the headline but reported
-    rasterizer.set_grad_sink(None)
-    refl_sink[0] = None
+    for view in views:
+        view.rasterizer.set_grad_sink(None)
     with torch.no_grad():
         for _ in range(2):
-            forward()
+            render(views[0], None, False)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
         nf = max(5, args.steps)
-        for _ in range(nf):
-            forward()
+        fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(nf + 1)]
+        t1 = time.perf_counter()
+        for i in range(nf):
+            fmarks[i].record()
+            render(views[0], None, False)
+        fmarks[nf].record()
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+        fwd_step_ms = [fmarks[i].elapsed_time(fmarks[i + 1]) for i in range(nf)]
 
-    # ---- secondary figure: the END-TO-END training step of the reference's loop (train.py:144-306):
-    # render -> (1 - lambda) L1 + lambda (1 - SSIM) against a synthetic ground-truth image -> backward -> gradient
-    # all-reduce -> Adam over all eight parameter groups.  Reported beside the headline, never as `value`.
-    full = None
-    if not args.no_full_step:
-        from gsr_train import DEFAULT_LRS, GaussianTrainState
-        from utils.loss_utils import photometric_loss
-        tensors = {k: v.detach().clone() for k, v in scene.p.items()}
-        scene.release()
-        # all learning rates 0: Adam does its full arithmetic and memory traffic but the scene stays the C3 configuration
-        # (with real rates the random target image changes opacities/scales within a few steps and the render cost drifts)
-        st = GaussianTrainState(tensors, dev, lrs={k: 0.0 for k in DEFAULT_LRS})
-        del tensors
-        fsink = st.grads.sink()
-        rasterizer.set_grad_sink(fsink)
-        frsink = st.grads.sink(names=("cubemap", "fail"))
-        fsunk = set(fsink) | set(frsink)
-        fenv = EnvMap(st.p["cubemap"], st.p["fail"])
-        gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
-
-        def full_step(it):
-            st.update_learning_rate(it)
-            st.grads.zero_except_(fsunk)
-            means2D.grad = None
-            base, radii, allmap, refl_map, gw = rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
-                                                           shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
-                                                           rotations=st.p["rotations"], env_scope_mask=scene.mask)
-            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, ct["viewmatrix"], HWK, ct["R"], ct["T"], grad_sink=frsink)
-            loss = photometric_loss(final, gt_image, 0.2)
-            loss.backward()
-            st.grads.all_reduce()
-            st.optimizer.step()
-            return loss
-
-        for i in range(args.warmup):
-            full_step(i + 1)
-        sync_all()
-        _gsr.profile_enable(True)
-        t2 = time.perf_counter()
-        for i in range(args.steps):
-            loss = full_step(args.warmup + i + 1)
-            if args.trace_steps:                      # development aid: per-step wall time (adds a sync per step)
-                torch.cuda.synchronize()
-                print("full step %d: %.3f ms (cumulative)" % (i, (time.perf_counter() - t2) * 1e3), file=sys.stderr, flush=True)
-        sync_all()
-        fdt = time.perf_counter() - t2
-        fstages = _gsr.profile_collect()
-        _gsr.profile_enable(False)
-        if dist_on:
-            tmax = torch.tensor([fdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            fdt = float(tmax.item())
-        full = {"ms_per_step": round(fdt / args.steps * 1e3, 4), "views_per_s": round(world * args.steps / fdt, 3),
-                "what": "render + L1/SSIM loss + backward + grad all-reduce + fused Adam (59 floats/Gaussian + cubemap), learning rates 0 so the workload stays C3",
-                "final_loss": round(float(loss.item()), 6),
-                "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in fstages.items() if v[1] > 0}}
+    scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
+    full = None if args.no_full_step else full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, world, views_total)
 
     if dist_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
+    value = views_total * args.steps / dt
 
     if rank == 0:
         R = info["R"]
         HW = W * H
+        nv = len(views)
         bwd_ms, bwd_n = stages["render_bwd"]
         # algorithmic bytes of ONE tile-render-backward launch (DESIGN.md §"Kernels"): per instance the 4-byte id, the
         # 80-byte render record and one 76-byte reduced gradient row; per pixel 64 bytes of upstream grads + saved state
         bytes_bwd = R * (4 + 80 + 76) + HW * 64
-        achieved = bytes_bwd / (bwd_ms / max(1, bwd_n) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        launch_s = bwd_ms / max(1, bwd_n) * 1e-3
+        achieved = bytes_bwd / launch_s / 1e9 if bwd_ms > 0 else 0.0
         fwd_bytes = 347 * P + 257 * R + 68 * HW     # SURVEY.md §8d, variant S
         bwdall_bytes = 871 * P + 156 * R + 64 * HW
         refl_bytes = (64 + 112) * HW
+        pmc = pmc_summary("surfel_render_bwd_wave_kernel", P, W, H)
+        roof = {"kernel": "surfel_render_bwd_wave_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"),
+                "traffic_source": pmc.get("source"), "avg_launch_ms": round(launch_s * 1e3, 4), "algorithmic_bytes_per_launch": bytes_bwd}
+        if pmc.get("insts_valu"):
+            rate = pmc["insts_valu"] / launch_s
+            roof["bound2"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 1),
+                              "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK_WAVE_INSTS_PER_S, 4),
+                              "wave_insts_valu_per_launch": pmc["insts_valu"], "wave_insts_salu_per_launch": pmc.get("insts_salu"),
+                              "what": "SQ_INSTS_VALU of the committed PMC pass / the launch time measured in this run, against one wave64 VALU "
+                                      "instruction per SIMD per 2 cycles; the kernel's mix (packed fp32, SGPR operands, DPP: ~4 cycles each, "
+                                      "tests/microbench/inst_cost.hip) puts its own issue bound at ~1.0 of the measured time (DESIGN.md)"}
         out = {
             "metric": "train_step_views_per_s (fwd+bwd, 1e6 Gaussians @1080p, surfel rasterizer + reflection path)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "C3: 1M Gaussians, 1920x1080, SH deg 3 + reflection/specular path (cubemap L=%d), fwd+bwd" % args.cubemap,
-                       "gaussians": P, "width": W, "height": H, "num_rendered": R, "views_per_step_per_gpu": 1,
-                       "parallelism": ("1 view per GPU + RCCL all-reduce of per-Gaussian grads" + (", overlapped with the next step (double-buffered)" if (overlap and not overlap_failed) else ", inside every step")) if dist_on else "single GPU"},
-            "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4),
-            "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stages.items() if v[1] > 0},
-            "step_algorithmic_GBps": round((fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
-            "roofline": {"kernel": "surfel_render_bwd_wave_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("surfel_render_bwd_wave_kernel", P, W, H),
-                         "avg_launch_ms": round(bwd_ms / max(1, bwd_n), 4), "algorithmic_bytes_per_launch": bytes_bwd},
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if dist_on else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("C4: batch of %d views of the C3 scene per step, sharded over the GPUs, one RCCL all-reduce of the per-Gaussian + "
+                                    "cubemap gradients inside every step" % views_total) if (dist_on or views_total > 1) else
+                                   "C3: 1M Gaussians, 1920x1080, SH deg 3 + reflection/specular path (cubemap L=%d), fwd+bwd" % args.cubemap,
+                       "gaussians": P, "width": W, "height": H, "num_rendered": R, "views_per_step": views_total,
+                       "views_per_step_per_gpu": nv,
+                       "parallelism": ("views sharded %d per GPU, gradients accumulated on device, all-reduce inside the step" % nv) if dist_on
+                       else "single GPU"},
+            "step_ms": percentiles(step_ms),
+            "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4), "forward_step_ms": percentiles(fwd_step_ms),
+            "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
+            "step_algorithmic_GBps": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+            "roofline": roof,
         }
-        if serial_ms is not None:
-            out["allreduce"] = {"payload_MB": round(scene_payload_mb, 1), "overlapped_ms_per_step": round(ms_per_step, 4),
-                                "serial_ms_per_step": round(serial_ms, 4),
-                                "what": "ms_per_step / value use the overlapped loop; serial = all-reduce inside every step"}
+        if dist_on:
+            out["allreduce"] = {"payload_MB": round(scene_payload_mb, 1), "inside_step": True,
+                                "overlapped_with_next_step_ms_per_step": None if overlap_ms is None else round(overlap_ms, 4),
+                                "what": "value / ms_per_step: all-reduce inside every step (what a training step pays); the overlapped figure "
+                                        "hides it behind the next step's rendering and is not achievable with an optimizer in the loop",
+                                "xgmi_model_ms": xgmi_model_ms(scene_payload_mb, world)}
         if full is not None:
             out["full_train_step"] = full
+        if not args.no_c5 and world == 1:
+            torch.cuda.empty_cache()
+            out["c5"] = c5_object(S, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(S, P, W, H, args.mu, args.cubemap)
         print(json.dumps(out), flush=True)
@@ -338,48 +322,204 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, P, W, H):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/r01_pmc_traffic.json,
-    produced by tests/pmc_summary.py from two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE --kernel-trace` runs).
-    Counters are in KB; FETCH_SIZE is doubled (gfx950 counts 32-B fetches as half, MI355X_MICROARCH.md HBM section).  None when
-    the file is absent or was collected on another configuration: the counters cannot be read from inside the timed process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
+def xgmi_model_ms(payload_mb, n):
+    """Analytic all-reduce time on MI355X's xGMI (7 point-to-point links x ~153 GB/s per GPU): a ring is bound
+    by one link, 2 (n-1)/n S / 153 GB/s; a direct full-mesh reduce-scatter + all-gather uses n-1 links at once, 2 (S/n) / 153 GB/s."""
+    S = payload_mb * 1e6
+    return {"ring": round(2 * (n - 1) / n * S / 153e9 * 1e3, 3), "full_mesh": round(2 * (S / n) / 153e9 * 1e3, 3)}
+
+
+def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, world, views_total):
+    """Secondary figure: the END-TO-END training step of the reference's loop (train.py:144-306) for this
+    rank's views: render -> (1 - lambda) L1 + lambda (1 - SSIM) against a synthetic ground-truth image -> backward (gradients
+    accumulated on the device) -> gradient all-reduce -> Adam over all eight parameter groups.  Never `value`."""
+    import _gsr
+    from gaussian_renderer import deferred_reflection
+    from gsr_train import DEFAULT_LRS, GaussianTrainState
+    from utils.loss_utils import photometric_loss
+    H, W = args.height, args.width
+    tensors = {k: v.detach().clone() for k, v in scene.p.items()}
+    mask = scene.mask
+    scene.release()
+    # all learning rates 0: Adam does its full arithmetic and memory traffic but the scene stays the C3 configuration
+    # (with real rates the random target image changes opacities/scales within a few steps and the render cost drifts)
+    st = GaussianTrainState(tensors, dev, lrs={k: 0.0 for k in DEFAULT_LRS})
+    del tensors
+    fsink, frsink = st.grads.sink(), st.grads.sink(names=("cubemap", "fail"))
+    fenv = EnvMap(st.p["cubemap"], st.p["fail"])
+    gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
+
+    def full_step(it):
+        st.update_learning_rate(it)
+        loss = None
+        for i, view in enumerate(views):
+            view.rasterizer.set_grad_sink(fsink, accumulate=i > 0)
+            means2D.grad = None
+            base, radii, allmap, refl_map, gw = view.rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
+                                                                shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
+                                                                rotations=st.p["rotations"], env_scope_mask=mask)
+            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
+                                              grad_sink=frsink, accumulate=i > 0)
+            loss = photometric_loss(final, gt_image, 0.2)
+            loss.backward()
+        st.grads.all_reduce()
+        st.optimizer.step()
+        return loss
+
+    for i in range(args.warmup):
+        full_step(i + 1)
+    sync_all()
+    _gsr.profile_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t2 = time.perf_counter()
+    for i in range(args.steps):
+        marks[i].record()
+        loss = full_step(args.warmup + i + 1)
+    marks[args.steps].record()
+    sync_all()
+    fdt = time.perf_counter() - t2
+    fstages = _gsr.profile_collect()
+    _gsr.profile_enable(False)
+    for view in views:
+        view.rasterizer.set_grad_sink(None)
+    if dist_on:
+        import torch.distributed as dist
+        tmax = torch.tensor([fdt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fdt = float(tmax.item())
+    nv = len(views)
+    return {"ms_per_step": round(fdt / args.steps * 1e3, 4), "views_per_s": round(views_total * args.steps / fdt, 3),
+            "step_ms": percentiles([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]),
+            "what": "render + L1/SSIM loss + backward + grad all-reduce + fused Adam (59 floats/Gaussian + cubemap), learning rates 0 so the workload stays C3",
+            "final_loss": round(float(loss.item()), 6),
+            "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * (1 if k == "adam" else nv)), 4) for k, v in fstages.items() if v[1] > 0}}
+
+
+def c5_object(S, dev, steps=5):
+    """BASELINE config C5 on this GPU: 5e6 Gaussians, 1920x1080, SH 3, the 3DGS rasterizer (variant G) with anti-aliasing and the
+    inverse-depth (depth-regularisation) backward enabled, forward + backward.  Per-stage hipEvent times and the HBM
+    roofline of its two dominant backward kernels (algorithmic bytes: SURVEY.md §8d, variant G)."""
+    import _gsr
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    P, W, H = 5_000_000, 1920, 1080
+    sc = S.make_scene(P, "G", seed=1005, mu=-5.3)
+    cam = S.make_camera(W, H)
+    t = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths", "normals")}
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
+    del sc
+    rast = GaussianRasterizer(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                                            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
+                                                            projmatrix=ct["projmatrix"], sh_degree=3, campos=ct["campos"], prefiltered=False,
+                                                            antialiasing=True, debug=False))
+    g = S.make_upstream_grads(H, W, 1005)
+    gc, gi, gn, gr = (torch.from_numpy(g[k]).to(dev) for k in ("dL_dcolor", "dL_dinvdepth", "dL_dnormal", "dL_drefl"))
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    R = [0]
+
+    def step():
+        for x in list(t.values()) + [means2D]:
+            x.grad = None
+        color, radii, invd, nmap, rmap = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"], normals=t["normals"],
+                                              refl_strengths=t["refl_strengths"], scales=t["scales"], rotations=t["rotations"])
+        R[0] = color.grad_fn.num_rendered
+        torch.autograd.backward([color, invd, nmap, rmap], [gc, gi, gn, gr])
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    _gsr.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    st = _gsr.profile_collect()
+    _gsr.profile_enable(False)
+    stage = {k: round(v[0] / steps, 4) for k, v in st.items() if v[1] > 0}
+    HW = W * H
+    kernels = {}
+    for name, key, nbytes in (("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P), ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW)):
+        if stage.get(key):
+            gbs = nbytes / (stage[key] * 1e-3) / 1e9
+            kernels[name] = {"bound": "hbm", "avg_launch_ms": stage[key], "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    del t, means2D
+    torch.cuda.empty_cache()
+    return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd", "num_rendered": R[0],
+            "ms_per_step": round(ms, 4), "steps": steps, "stage_ms_per_step": stage, "kernel_sum_ms": round(sum(stage.values()), 4), "roofline": kernels}
+
+
+def pmc_summary(kernel, P, W, H):
+    """Per-launch counters of `kernel` from the committed PMC passes of this same command (profiles/r02_pmc_summary.json, written
+    by tests/pmc_summary.py from separate `rocprofv3 --pmc ... --kernel-trace` runs on the GPU box).  FETCH_SIZE / WRITE_SIZE are in
+    KB; FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64, MI355X_MICROARCH.md HBM section).  The counters cannot be read
+    from inside the timed process, so they are QUOTED (source says from where); empty when the file is absent or was collected on
+    another configuration."""
+    if not os.path.exists(PMC_FILE):
+        return {}
+    with open(PMC_FILE) as f:
         d = json.load(f)
     cfg = d.get("_config", {})
     if (cfg.get("P"), cfg.get("W"), cfg.get("H")) != (P, W, H):
-        return None
+        return {}
     for k, v in d.items():
         if kernel in k:
-            return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
-    return None
+            out = {"source": "quoted from %s (rocprofv3 --pmc passes of `%s`, %s)" % (os.path.relpath(PMC_FILE, ROOT), cfg.get("cmd", "bench.py"), cfg.get("when", "this round"))}
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                out["traffic"] = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+            if "SQ_INSTS_VALU" in v:
+                out["insts_valu"] = int(v["SQ_INSTS_VALU"])
+            if "SQ_INSTS_SALU" in v:
+                out["insts_salu"] = int(v["SQ_INSTS_SALU"])
+            return out
+    return {}
 
 
 def cpu_baseline(S, P, W, H, mu, L):
-    """The CPU oracle (test infrastructure, oracle/) timed on this host: ONE full step of the same workload
-    (rasterizer fwd+bwd + cubemap lookup fwd+bwd), OpenMP over all host cores."""
+    """The CPU oracle (test infrastructure, oracle/) timed on this host: ONE full step of the same workload (rasterizer fwd+bwd +
+    cubemap lookup fwd+bwd), OpenMP over all host cores; and a bounded single-thread sample: the same scene statistics at 1/256
+    of the size (Gaussians / 256, image / 16 per side, scales x 16, hence the same tiles per Gaussian and list length per tile),
+    OMP_NUM_THREADS = 1, extrapolated x 256."""
+    import ctypes
     from oracle import oracle as orc
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import scene_kwargs
-    kw, cam, sc = scene_kwargs("S", P, W, H, 1003, mu, 3, (0, 0, 0))
-    g = S.make_upstream_grads(H, W, 1003)
-    tex, fail = S.make_cubemap(L, 3, 1003)
-    o = orc.SurfelOracle(np.float32)
-    o.forward(**dict(kw, means3D=kw["means3D"][:1000], opacities=kw["opacities"][:1000], shs=kw["shs"][:1000],
-                     refl_strengths=kw["refl_strengths"][:1000], scales=kw["scales"][:1000], rotations=kw["rotations"][:1000],
-                     env_scope_mask=kw["env_scope_mask"][:1000]))  # warm the library
-    t = time.perf_counter()
-    ref = o.forward(**kw)
-    dirs = np.ascontiguousarray(np.moveaxis(ref["allmap"][2:5], 0, -1).reshape(-1, 3))
-    c = orc.cubemap_forward(dirs, tex, fail)
-    orc.cubemap_backward(np.ascontiguousarray(np.broadcast_to(g["dL_dcolor"].reshape(3, -1), c.shape)), dirs, tex)
-    o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
-    dt = time.perf_counter() - t
-    return {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "one full C3 step (1M Gaussians, 1920x1080, R=%d) through the CPU oracle (OpenMP, all host cores), %.1f s" % (
-                ref["num_rendered"], dt)}
+
+    def one_step(Pn, Wn, Hn, mun, seed):
+        kw, cam, sc = scene_kwargs("S", Pn, Wn, Hn, seed, mun, 3, (0, 0, 0))
+        g = S.make_upstream_grads(Hn, Wn, seed)
+        tex, fail = S.make_cubemap(L, 3, seed)
+        o = orc.SurfelOracle(np.float32)
+        o.forward(**dict(kw, means3D=kw["means3D"][:1000], opacities=kw["opacities"][:1000], shs=kw["shs"][:1000],
+                         refl_strengths=kw["refl_strengths"][:1000], scales=kw["scales"][:1000], rotations=kw["rotations"][:1000],
+                         env_scope_mask=kw["env_scope_mask"][:1000]))  # warm the library
+        t = time.perf_counter()
+        ref = o.forward(**kw)
+        dirs = np.ascontiguousarray(np.moveaxis(ref["allmap"][2:5], 0, -1).reshape(-1, 3))
+        c = orc.cubemap_forward(dirs, tex, fail)
+        orc.cubemap_backward(np.ascontiguousarray(np.broadcast_to(g["dL_dcolor"].reshape(3, -1), c.shape)), dirs, tex)
+        o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
+        return time.perf_counter() - t, ref["num_rendered"]
+
+    dt, R = one_step(P, W, H, mu, 1003)
+    out = {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": "one full C3 step (1M Gaussians, 1920x1080, R=%d) through the CPU oracle (OpenMP, all host cores), %.1f s" % (R, dt)}
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_get_max_threads.restype = ctypes.c_int
+        before = omp.omp_get_max_threads()
+        omp.omp_set_num_threads(1)
+        try:
+            f = 16
+            dts, Rs = one_step(max(1000, P // (f * f)), W // f, H // f, mu + math.log(f), 1003)
+        finally:
+            omp.omp_set_num_threads(before)
+        out["single_thread"] = {"value": round(1.0 / (dts * f * f), 6), "unit": "views/s", "cores": 1, "kind": "port",
+                                "sample": "1/%d of C3 with the same per-tile statistics (%d Gaussians, scales x %d, %dx%d, R=%d), "
+                                          "OMP_NUM_THREADS=1, %.1f s, extrapolated x %d" % (f * f, max(1000, P // (f * f)), f, W // f, H // f, Rs, dts, f * f)}
+    except OSError:
+        pass
+    return out
 
 
 if __name__ == "__main__":

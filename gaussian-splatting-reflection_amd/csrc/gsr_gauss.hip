@@ -88,11 +88,6 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
-	// SH rows of the wave's 64 Gaussians through LDS (coalesced; see stage_sh_rows) when the full 16-coefficient rows are needed
-	__shared__ float4 s_sh[4 * GSR_SH_LDS_F4_PER_WAVE];
-	float4* sh_wave = s_sh + (threadIdx.x >> 6) * GSR_SH_LDS_F4_PER_WAVE;
-	const bool sh_staged = colors_precomp == nullptr && M == 16 && D == 3;
-	if (sh_staged && (idx & ~63) < P) stage_sh_rows(shs, idx & ~63, P, sh_wave);
 	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
@@ -150,8 +145,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 		const float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
 		const float len = sqrtf(dx * dx + dy * dy + dz * dz);
 		ShRow s;
-		if (sh_staged) load_sh_staged(sh_wave, s);
-		else load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+		load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 		const F3 c = sh_eval(D, s, dx / len, dy / len, dz / len);
 		g.clamped[idx] = (uint8_t)((c.x < 0 ? 1 : 0) | (c.y < 0 ? 2 : 0) | (c.z < 0 ? 4 : 0));
 		cr = fmaxf(c.x, 0.0f); cg = fmaxf(c.y, 0.0f); cb = fmaxf(c.z, 0.0f);

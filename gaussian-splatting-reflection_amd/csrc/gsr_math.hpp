@@ -98,39 +98,9 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int idx, 
 	}
 }
 
-// Coalesced form of load_sh for M = 16 at the full degree (192-byte rows, the largest per-Gaussian stream): with one row
-// per lane a float4 load touches 64 different cache lines per instruction, every line three or four times over the twelve
-// loads.  Here the wave reads ITS 64 consecutive rows (12 KB, contiguous) with lane-contiguous float4 loads into LDS and each
-// lane then picks its row up from there.  Rows are 13 float4 apart in LDS (208 bytes): 52 l mod 64 hits every fourth bank
-// exactly once over 16 lanes, so the ds_read_b128 of a row walk are conflict-free.  Wave-local (no workgroup barrier): a
-// wave's DS instructions execute in issue order, the wave_barrier only pins the compiler's ordering.  Every lane of the wave
-// must take part, also those whose Gaussian is culled or beyond P.
-#define GSR_SH_LDS_F4_PER_WAVE (64 * 13)
-__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int wave_first, int P, float4* __restrict__ lds_wave) {
-	const int lane = threadIdx.x & 63;
-	const float4* src = reinterpret_cast<const float4*>(shs) + (size_t)wave_first * 12;
-	const int nf4 = min(64, P - wave_first) * 12;
-	float4 t[12];
-#pragma unroll
-	for (int j = 0; j < 12; j++) {
-		const int f = lane + 64 * j;
-		t[j] = f < nf4 ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-	}
-#pragma unroll
-	for (int j = 0; j < 12; j++) {
-		const int f = lane + 64 * j;
-		lds_wave[f + f / 12] = t[j];          // row f / 12, float4 f % 12 of it, rows 13 float4 apart
-	}
-	__builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void load_sh_staged(const float4* __restrict__ lds_wave, ShRow& s) {
-	const float4* r4 = lds_wave + (threadIdx.x & 63) * 13;
-#pragma unroll
-	for (int q = 0; q < 12; q++) {
-		const float4 t = r4[q];
-		s.v[4 * q + 0] = t.x; s.v[4 * q + 1] = t.y; s.v[4 * q + 2] = t.z; s.v[4 * q + 3] = t.w;
-	}
-}
+// (Measured and dropped: staging the wave's 64 SH rows through LDS with lane-contiguous float4 loads — 12 KB per wave, rows 13
+// float4 apart so that the row walk is bank-conflict-free — instead of this one-row-per-lane walk.  surfel_preprocess_kernel
+// at C3: 0.105 ms before, 0.109 ms after; the strided walk is absorbed by L1/L2 and the kernel is not bound by it.)
 
 // computeColorFromSH forward (DSR/DGR forward.cu:20-71): returns the unclamped colour + 0.5.
 __device__ __forceinline__ F3 sh_eval(int deg, const ShRow& s, float x, float y, float z) {

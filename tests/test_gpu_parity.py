@@ -2,14 +2,15 @@
 oracle on identical seeded inputs.  Bars (BASELINE.md §4 / north star):
   * integer / index work bit-exact (radii, tile counts, offsets, sort keys, point list, tile ranges)
   * render PSNR >= 50 dB (we also assert much tighter absolute bounds)
-  * gradients within 1e-4 relative (max-norm per tensor)
+  * gradients within 1e-4 relative: max-norm per tensor AND elementwise (|a-b| <= 1e-4 |b| + 1e-6 max|b|, failing
+    fraction <= 1e-5: helpers.grad_gate)
 n_contrib (per-pixel last contributor) depends on exp() ulps through the alpha < 1/255 and T < 1e-4
 thresholds; it is compared with a mismatch budget of 1e-4 of the pixels and documented in DESIGN.md.
 """
 import numpy as np
 import pytest
 
-from helpers import HipGauss, HipSurfel, S, psnr, rel_maxnorm, scene_kwargs
+from helpers import GATE_BUDGET, HipGauss, HipSurfel, S, grad_gate, psnr, rel_maxnorm, scene_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +63,8 @@ def _run_surfel(P, W, H, seed, mu, sh_degree, bg, mask_radius=0.0, backward=True
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_drefl_strengths", "dL_dscales", "dL_drotations"):
         err = rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k])
         assert err <= GRAD_TOL, (k, err)
+        bad = grad_gate(gh[k], gr[k], GRAD_TOL)
+        assert bad <= GATE_BUDGET, (k, "elementwise gate", bad)
 
 
 def _run_gauss(P, W, H, seed, mu, sh_degree, bg, antialiasing=False, backward=True):
@@ -89,6 +92,8 @@ def _run_gauss(P, W, H, seed, mu, sh_degree, bg, antialiasing=False, backward=Tr
     for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dnormals", "dL_drefl_strengths", "dL_dscales", "dL_drotations"):
         err = rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k])
         assert err <= GRAD_TOL, (k, err)
+        bad = grad_gate(gh[k], gr[k], GRAD_TOL)
+        assert bad <= GATE_BUDGET, (k, "elementwise gate", bad)
 
 
 # ---- BASELINE config C1: 10k / 256x256 / SH deg 0, forward only (plumbing) ----
