@@ -477,9 +477,10 @@ def pmc_summary(kernel, P, W, H):
 
 def cpu_baseline(S, P, W, H, mu, L):
     """The CPU oracle (test infrastructure, oracle/) timed on this host: ONE full step of the same workload (rasterizer fwd+bwd +
-    cubemap lookup fwd+bwd), OpenMP over all host cores; and a bounded single-thread sample: the same scene statistics at 1/256
-    of the size (Gaussians / 256, image / 16 per side, scales x 16, hence the same tiles per Gaussian and list length per tile),
-    OMP_NUM_THREADS = 1, extrapolated x 256."""
+    cubemap lookup fwd+bwd), OpenMP over all host cores; and a bounded single-thread sample: the same scene statistics at 1/4
+    of the size (Gaussians / 4, image / 2 per side, scales x 2, hence the same tiles per Gaussian and list length per tile),
+    OMP_NUM_THREADS = 1, extrapolated x 4.  (The oracle's backward accumulates with `omp atomic`: it scales poorly to hundreds
+    of cores, which is why the single-thread figure is reported beside the all-core one.)"""
     import ctypes
     from oracle import oracle as orc
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -510,7 +511,7 @@ def cpu_baseline(S, P, W, H, mu, L):
         before = omp.omp_get_max_threads()
         omp.omp_set_num_threads(1)
         try:
-            f = 16
+            f = 2          # 1/4 of the step: ~10 s of single-thread work
             dts, Rs = one_step(max(1000, P // (f * f)), W // f, H // f, mu + math.log(f), 1003)
         finally:
             omp.omp_set_num_threads(before)

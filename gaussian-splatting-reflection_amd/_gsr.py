@@ -106,6 +106,24 @@ def _load():
 
 lib = _load()
 
+
+def compiled_binding():
+    """The optional compiled torch/pybind binding (csrc/gsr_torch_binding.cpp -> _gsr_C.so), selected with GSR_BINDING=pybind; None
+    otherwise (the default ctypes path).  Selected but not built is an error, not a silent fallback."""
+    if os.environ.get("GSR_BINDING", "ctypes") != "pybind":
+        return None
+    import importlib.util
+    path = os.path.join(_HERE, "_gsr_C.so")
+    if not os.path.exists(path):
+        raise ImportError(f"GSR_BINDING=pybind but {path} is not built: run `python {os.path.join(_HERE, 'csrc', 'build.py')} --binding`")
+    spec = importlib.util.spec_from_file_location("_gsr_C", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+PYBIND = compiled_binding()
+
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
             "gsr_deferred_reflection_backward_accum", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",

@@ -79,5 +79,39 @@ def build(force=False, verbose=True):
     return OUT
 
 
+BINDING_OUT = os.path.join(PKG, "_gsr_C.so")
+
+
+def build_binding(force=False, verbose=True):
+    """Optional compiled torch/pybind binding (gsr_torch_binding.cpp -> _gsr_C.so next to libgsr_hip.so): marshaling only, links
+    the C-ABI library.  The package works without it (ctypes, _gsr.py); GSR_BINDING=pybind selects it."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    build(verbose=verbose)
+    src = os.path.join(HERE, "gsr_torch_binding.cpp")
+    h = hashlib.sha256(open(src, "rb").read() + open(os.path.join(HERE, "..", "..", "include", "gsr_hip.h"), "rb").read() + torch.__version__.encode())
+    stamp = os.path.join(OBJ_DIR, "binding_digest.txt")
+    if not force and os.path.exists(BINDING_OUT) and os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest():
+        return BINDING_OUT
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    libdirs = ce.library_paths()
+    cmd = [HIPCC, "-x", "c++", "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_gsr_C",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-unused-result"]
+    cmd += ["-I" + i for i in inc] + [src, "-o", BINDING_OUT] + ["-L" + d for d in libdirs] + ["-Wl,-rpath," + d for d in libdirs]
+    cmd += ["-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip", "-L" + PKG, "-lgsr_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"binding build failed:\n{r.stdout}\n{r.stderr[-4000:]}")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(stamp, "w") as fh:
+        fh.write(h.hexdigest())
+    if verbose:
+        print(f"built {BINDING_OUT}")
+    return BINDING_OUT
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--binding" in sys.argv:
+        build_binding(force="--force" in sys.argv)

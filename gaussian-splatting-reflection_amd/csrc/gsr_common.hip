@@ -62,6 +62,8 @@ static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
 static int g_opt_dev = 0;
 int option_dev() { return g_opt_dev; }
+static int g_opt_sort_driver = GSR_ONESWEEP_DRIVER;
+int option_sort_driver() { return GSR_ONESWEEP_DRIVER && g_opt_sort_driver; }
 
 // getHigherMsb (DSR/DGR rasterizer_impl.cu:35-50)
 uint32_t higher_msb(uint32_t n) {
@@ -109,26 +111,25 @@ static size_t scan_part_bytes(size_t P) {
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	return (std::max(a, b) + 255) & ~(size_t)255;
 }
+// temp bytes: the larger of the two drivers' needs, so that the runtime switch (option_sort_driver) never changes a workspace size
 static size_t depth_sort_bytes(size_t P) {
-	size_t c = 0;
+	size_t c = 0, d = 0;
 	if (P <= SORT_MAX_ITEMS)
 		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
 		                                            (uint32_t*)nullptr, P, 0u, 31u, 0);
-	else
-		(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-		                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
-	return c;
+	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
+	                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
+	return std::max(c, d);
 }
 size_t scan_temp_bytes(size_t P) { return scan_part_bytes(P) + depth_sort_bytes(P); }
 size_t sort_temp_bytes(size_t R, int end_bit) {
-	size_t bytes = 0;
+	size_t bytes = 0, pub = 0;
 	if (R <= SORT_MAX_ITEMS)
 		(void)onesweep_sort_pairs<TILE_SORT_SHAPE>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, R,
 		                                           0u, (unsigned)end_bit, 0);
-	else
-		(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
-		                                            end_bit, 0, false);
-	return bytes;
+	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, pub, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
+	                                            end_bit, 0, false);
+	return std::max(bytes, pub);
 }
 
 GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_floats, size_t scan_bytes, size_t* total) {
@@ -358,7 +359,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// tiles_touched taken in that order
 		StageTimer st_(GSR_STAGE_SORT, stream);
 		size_t tmp = geom.depth_sort_bytes;
-		if ((size_t)P <= SORT_MAX_ITEMS)   // look-back state already cleared by the preprocess kernel
+		if (option_sort_driver() && (size_t)P <= SORT_MAX_ITEMS)   // look-back state already cleared by the preprocess kernel
 			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, true));
 		else
@@ -387,14 +388,14 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	if (R == 0) GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));   // otherwise emit_tiles_kernel clears them
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
-		const bool own_sort = (size_t)R <= SORT_MAX_ITEMS;
+		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
 		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
-		if ((size_t)R <= SORT_MAX_ITEMS)
+		if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS)
 			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
 			                                                  (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
 		else
@@ -464,6 +465,7 @@ extern "C" int gsr_version(void) { return 100; }
 extern "C" int gsr_set_option(const char* name, int value) {
 	if (std::string(name) == "cull") { g_opt_cull = value ? 1 : 0; return 0; }
 	if (std::string(name) == "dev") { g_opt_dev = value; return 0; }
+	if (std::string(name) == "sort_driver") { g_opt_sort_driver = value ? 1 : 0; return 0; }   // 0: public rocprim::radix_sort_pairs everywhere
 	set_error("gsr_set_option: unknown option '%s'", name);
 	return GSR_E_INVALID;
 }

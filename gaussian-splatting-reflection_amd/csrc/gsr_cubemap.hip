@@ -811,6 +811,17 @@ struct ReflScratch {
 static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
                             bool pre_cleared = false) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
+	if (temp == nullptr) {   // size query: the larger of the two drivers' needs (the runtime switch never changes a scratch size)
+		size_t own = 0, pub = 0;
+		if (key_bits > 16 && key_bits <= 18) (void)onesweep_sort_pairs<1024, 8, 9>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+		else if (key_bits > 18 && key_bits <= 20) (void)onesweep_sort_pairs<1024, 8, 10>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+		else (void)onesweep_sort_pairs<1024, 8, 8>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+		(void)rocprim::radix_sort_pairs(nullptr, pub, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+		bytes = own > pub ? own : pub;
+		return hipSuccess;
+	}
+	if (!option_sort_driver())   // gsr_set_option("sort_driver", 0) or an unknown rocPRIM release: the public entry point
+		return rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
 	if (key_bits > 16 && key_bits <= 18)
 		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
 	if (key_bits > 18 && key_bits <= 20)

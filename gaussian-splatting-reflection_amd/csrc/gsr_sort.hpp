@@ -11,16 +11,37 @@
 // (Folding the histogram scans into the histogram kernel's last workgroup — ticket counter + __threadfence, the classic
 // "last block" pattern — was measured and is far slower: 0.30 ms against 0.185 ms for the two-level sort.  An agent-scope
 // release fence writes back and invalidates the XCD's L2 on this multi-die part, once per workgroup.)
+//
+// What this file assumes about rocPRIM's PRIVATE device code, and how each assumption is guarded:
+//   * the signatures of detail::onesweep_histograms / onesweep_scan_histograms / onesweep_iteration and of block_id_wrapper:
+//     checked by the compiler; the driver is only compiled for the rocPRIM release it was written against
+//     (GSR_ONESWEEP_DRIVER below), any other release takes the public rocprim::radix_sort_pairs for every sort;
+//   * an all-zero onesweep_lookback_state means "empty" and is 4 bytes: static_asserts below;
+//   * the temp layout is THIS driver's own (it passes every pointer explicitly), not rocPRIM's;
+//   * a runtime switch (gsr_set_option("sort_driver", 0)) forces the public path, and tests/test_gpu_api_paths.py asserts that
+//     both drivers produce bit-identical point lists and tile ranges at small and full size.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/rocprim_version.hpp>
+
+#if ROCPRIM_VERSION / 100 == 4002      // rocPRIM 4.2.x (ROCm 7.2): the release whose detail:: entry points are used below
+#define GSR_ONESWEEP_DRIVER 1
+#else
+#define GSR_ONESWEEP_DRIVER 0          // unknown internals: public rocprim::radix_sort_pairs only
+#endif
 
 namespace gsr {
 
+int option_sort_driver();   // 1 (default): one-clear Onesweep driver of this file; 0: rocprim::radix_sort_pairs (gsr_set_option("sort_driver", ...))
+
+#if GSR_ONESWEEP_DRIVER
 using SortOffset = unsigned int;
 using SortBlockId = rocprim::detail::block_id_wrapper<unsigned int, true>;
 using SortLookback = rocprim::detail::onesweep_lookback_state;
+static_assert(sizeof(SortLookback) == 4, "onesweep_lookback_state is expected to be one 32-bit word (flag in the top two bits)");
+static_assert(SortLookback::EMPTY == 0, "a zero-filled look-back state must mean EMPTY: the driver clears the states with zeros");
 
 template <unsigned BS, unsigned IPT, unsigned BITS>
 __global__ void __launch_bounds__(BS) sort_histogram_kernel(const uint32_t* keys, SortOffset* digit_counts, SortOffset size, SortOffset full_blocks,
@@ -121,5 +142,15 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 	}
 	return hipGetLastError();
 }
+#else   // !GSR_ONESWEEP_DRIVER: nothing to clear, and the sort entry point reports "not available" so that callers take rocPRIM's own
+template <unsigned BS, unsigned IPT, unsigned BITS>
+size_t onesweep_cleared_bytes(size_t, unsigned, unsigned) { return 0; }
+__device__ __forceinline__ void sort_clear_region(void*, size_t, size_t, size_t) {}
+template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
+hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t*, uint32_t*, ValuesIn, Value*, size_t, unsigned, unsigned, hipStream_t, bool = false) {
+	if (temp == nullptr) bytes = 0;
+	return hipErrorNotSupported;
+}
+#endif
 
 }  // namespace gsr

@@ -25,6 +25,11 @@ def _dev(t, dev):
 def rasterize_gaussians(background, means3D, colors, normals, refl_strengths, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
                         antialiasing, debug):
+    if _gsr.PYBIND is not None:      # GSR_BINDING=pybind: the compiled marshaling (csrc/gsr_torch_binding.cpp) instead of ctypes
+        return _gsr.PYBIND.gauss_rasterize_gaussians(background, means3D, colors, normals, refl_strengths, opacity, scales, rotations,
+                                                     float(scale_modifier), cov3D_precomp, viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy),
+                                                     int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered),
+                                                     bool(antialiasing), bool(debug))
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     if not means3D.is_cuda:
@@ -61,6 +66,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, normals, re
                                  antialiasing, debug, *, grad_sink=None, accumulate=False):
     if grad_sink or accumulate:
         raise NotImplementedError("gradient sinks are provided for the surfel rasterizer (the one the training path calls) only")
+    if _gsr.PYBIND is not None:
+        e = lambda t: t if t is not None else torch.empty(0, device=means3D.device)
+        return _gsr.PYBIND.gauss_rasterize_gaussians_backward(
+            background, means3D, radii, colors, normals, refl_strengths, opacities, scales, rotations, float(scale_modifier), cov3D_precomp,
+            viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color, e(dL_dout_invdepth), dL_dout_normal_map,
+            e(dL_dout_refl_strength_map), sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(antialiasing), bool(debug))
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
@@ -101,6 +112,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, normals, re
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
+    if _gsr.PYBIND is not None:
+        return _gsr.PYBIND.mark_visible(means3D, viewmatrix, projmatrix)
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
     if P != 0:

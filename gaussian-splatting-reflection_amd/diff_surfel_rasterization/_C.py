@@ -21,6 +21,11 @@ SINKABLE = frozenset(("means3D", "shs", "opacities", "scales", "rotations", "ref
 def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations, scale_modifier,
                         transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
+    if _gsr.PYBIND is not None:      # GSR_BINDING=pybind: the compiled marshaling (csrc/gsr_torch_binding.cpp) instead of ctypes
+        return _gsr.PYBIND.surfel_rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations,
+                                                      float(scale_modifier), transMat_precomp, viewmatrix, projmatrix, float(tan_fovx),
+                                                      float(tan_fovy), int(image_height), int(image_width), sh, int(degree), campos,
+                                                      bool(prefiltered), bool(debug))
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("refl_strengths", refl_strengths),
@@ -68,6 +73,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     gsr_dist.FlatGrads); the per-Gaussian backward kernel then writes — or, with accumulate=True, ADDS — those gradients
     straight into them and the corresponding entries of the return tuple are those same tensors.  The sink belongs to
     this call: there is no module-level state."""
+    if _gsr.PYBIND is not None and not grad_sink:
+        return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
+            background, means3D, radii, colors, refl_strengths, scales, rotations, float(scale_modifier), transMat_precomp, viewmatrix, projmatrix,
+            float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_others,
+            dL_dout_refl_strength_map if dL_dout_refl_strength_map is not None else torch.empty(0, device=means3D.device), sh, int(degree), campos,
+            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors), ("scales", scales),
                     ("rotations", rotations), ("transMat_precomp", transMat_precomp), ("viewmatrix", viewmatrix),
                     ("projmatrix", projmatrix), ("sh", sh), ("campos", campos), ("binningBuffer", binningBuffer),
@@ -120,6 +131,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
+    if _gsr.PYBIND is not None:
+        return _gsr.PYBIND.mark_visible(means3D, viewmatrix, projmatrix)
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
     if P != 0:
