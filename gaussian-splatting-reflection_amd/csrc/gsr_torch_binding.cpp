@@ -11,8 +11,9 @@
 // std::function resize callbacks are one C callback.
 // Build: python gaussian-splatting-reflection_amd/csrc/build.py --binding   (hipcc, links libgsr_hip.so).  Select with GSR_BINDING=pybind.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/HIPContext.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <tuple>
 #include <vector>
@@ -45,7 +46,9 @@ struct FloatArg {
 		p = keep.data_ptr<float>();
 	}
 };
-void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// (PyTorch-ROCm presents HIP devices as "cuda": the guards and stream getters are the ...MasqueradingAsCUDA flavours)
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+void* current_stream(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 void check(int rc, const char* what) { TORCH_CHECK(rc >= 0, what, " failed (code ", rc, "): ", gsr_last_error()); }
 
 #define REQUIRE_CUDA(t) TORCH_CHECK((t).is_cuda(), #t " must be a CUDA tensor")
@@ -63,7 +66,7 @@ SurfelForward(const torch::Tensor& background, const torch::Tensor& means3D, con
 	REQUIRE_CUDA(background); REQUIRE_CUDA(means3D); REQUIRE_CUDA(colors); REQUIRE_CUDA(refl_strengths); REQUIRE_CUDA(opacity); REQUIRE_CUDA(scales);
 	REQUIRE_CUDA(rotations); REQUIRE_CUDA(transMat_precomp); REQUIRE_CUDA(viewmatrix); REQUIRE_CUDA(projmatrix); REQUIRE_CUDA(sh); REQUIRE_CUDA(campos);
 	const int P = (int)means3D.size(0), H = image_height, W = image_width;
-	const c10::hip::HIPGuard guard(means3D.device());
+	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto out_color = torch::empty({3, H, W}, f), out_others = torch::empty({8, H, W}, f), out_refl = torch::empty({1, H, W}, f);
 	auto radii = torch::empty({P}, means3D.options().dtype(torch::kInt32)), gw = torch::empty({P}, f);
@@ -96,7 +99,7 @@ SurfelBackward(const torch::Tensor& background, const torch::Tensor& means3D, co
                const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug) {
 	const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
 	const int M = sh.numel() ? (int)sh.size(1) : 0;
-	const c10::hip::HIPGuard guard(means3D.device());
+	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto mk = [&](std::vector<int64_t> shape) { return P ? torch::empty(shape, f) : torch::zeros(shape, f); };   // the library writes every element
 	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D = mk({P, 3}), dL_dcolors = mk({P, 3}), dL_dnormal = mk({P, 3}), dL_dopacity = mk({P, 1}),
@@ -129,7 +132,7 @@ GaussForward(const torch::Tensor& background, const torch::Tensor& means3D, cons
 	TORCH_CHECK(means3D.ndimension() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");
 	REQUIRE_CUDA(means3D);
 	const int P = (int)means3D.size(0), H = image_height, W = image_width;
-	const c10::hip::HIPGuard guard(means3D.device());
+	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto out_color = torch::empty({3, H, W}, f), out_normal = torch::empty({3, H, W}, f), out_inv = torch::empty({1, H, W}, f), out_refl = torch::empty({1, H, W}, f);
 	auto radii = torch::empty({P}, means3D.options().dtype(torch::kInt32));
@@ -156,7 +159,7 @@ GaussBackward(const torch::Tensor& background, const torch::Tensor& means3D, con
               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool antialiasing, const bool debug) {
 	const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
 	const int M = sh.numel() ? (int)sh.size(1) : 0;
-	const c10::hip::HIPGuard guard(means3D.device());
+	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto mk = [&](std::vector<int64_t> shape) { return P ? torch::empty(shape, f) : torch::zeros(shape, f); };
 	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D = mk({P, 3}), dL_dmeans2D_pixels = mk({P, 3}), dL_dcolors = mk({P, 3}), dL_dnormals = mk({P, 3}),
@@ -190,7 +193,7 @@ torch::Tensor MarkVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
 	const int P = (int)means3D.size(0);
 	auto present = torch::zeros({P}, means3D.options().dtype(torch::kBool));
 	if (P != 0) {
-		const c10::hip::HIPGuard guard(means3D.device());
+		const DeviceGuard guard(means3D.device());
 		FloatArg m3(means3D, "means3D"), vm(viewmatrix, "viewmatrix"), pm(projmatrix, "projmatrix");
 		check(gsr_mark_visible(P, m3.p, vm.p, pm.p, reinterpret_cast<uint8_t*>(present.data_ptr<bool>()), current_stream(means3D)), "gsr_mark_visible");
 	}

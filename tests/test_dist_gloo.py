@@ -140,3 +140,41 @@ def test_two_rank_double_buffered_allreduce(tmp_path):
         b = got[k][n * 3: n * 3 + 7]
         assert torch.all(a == float(rsum * (k + 1)))
         assert torch.equal(b, torch.arange(7, dtype=torch.float32) * rsum + world * k)
+
+
+def _c4_worker(rank, world, port, n_views, n, out_dir):
+    """The step of bench.py at N > 1 (BASELINE config C4): rank r takes views r, r + N, ...; its FIRST view overwrites the
+    gradient sinks, every further view ADDS to them (what the backward kernels do with accumulate = False / True), then ONE
+    all-reduce of the flat buffer inside the step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_dist import FlatGrads, shard_views
+    params = {"means3D": torch.zeros(n, 3, requires_grad=True), "shs": torch.zeros(n, 16, 3, requires_grad=True), "cubemap": torch.zeros(6, 3, 4, 4, requires_grad=True)}
+    fg = FlatGrads(params)
+    fg.flat.fill_(float("nan"))                    # stale content of the previous step: the first view must overwrite it
+    sink = fg.sink(names=("means3D", "shs", "cubemap"))
+    for i, v in enumerate(shard_views(n_views, rank, world)):
+        for j, k in enumerate(sorted(sink)):
+            g = torch.full(sink[k].shape, float((v + 1) * (j + 2)))
+            sink[k].copy_(g) if i == 0 else sink[k].add_(g)
+    fg.all_reduce()
+    if rank == 0:
+        torch.save(fg.flat.clone(), os.path.join(out_dir, "c4.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_views", [(2, 8), (2, 3)])
+def test_c4_batch_accumulate_then_one_allreduce(tmp_path, world, n_views):
+    n = 500
+    port = 33500 + (os.getpid() % 2000) + n_views
+    mp.spawn(_c4_worker, args=(world, port, n_views, n, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "c4.pt"), weights_only=True)
+    tot = sum(v + 1 for v in range(n_views))
+    sizes = {"cubemap": 6 * 3 * 4 * 4, "means3D": n * 3, "shs": n * 48}
+    off = {"means3D": 0, "shs": n * 3, "cubemap": n * 3 + n * 48}
+    for j, k in enumerate(sorted(sizes)):
+        part = got[off[k]: off[k] + sizes[k]]
+        assert torch.all(part == float(tot * (j + 2))), k

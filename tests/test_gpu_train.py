@@ -262,3 +262,65 @@ def test_training_loop_converges_and_survives_densification():
     # does) removes many of the synthetic scene's half-hidden surfels at once, after which the fit improves again
     assert np.mean(losses[16:20]) < 0.8 * np.mean(losses[:3]), (losses[:3], losses[16:20])
     assert np.mean(losses[-3:]) < np.mean(losses[20:23]), (losses[20:23], losses[-3:])
+
+
+def test_world_size_one_rccl_step_backward_sink_allreduce_adam():
+    """The whole N-GPU data path on one GPU with the real backend: HIP backward -> gradient sink (two views accumulated on the
+    device) -> ONE all-reduce over RCCL (backend "nccl", world size 1) -> fused Adam.  Against the same two views through plain
+    autograd accumulation and no process group."""
+    import torch.distributed as dist
+    import gsr_synth as S
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussian_renderer import deferred_reflection
+    from gsr_train import GaussianTrainState
+    from utils.loss_utils import photometric_loss
+    P, W, H, L = 4000, 160, 120, 16
+    sc = S.make_scene(P, "S", seed=19, mu=-2.6)
+    tex, fail = S.make_cubemap(L, 3, 19)
+    cams = [S.look_at_camera(W, H, eye=(0.3 * k, -0.1 * k, -0.4)) for k in range(2)]
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
+    tensors = {k: torch.from_numpy(sc[k]) for k in names}
+    tensors["cubemap"], tensors["fail"] = torch.from_numpy(tex), torch.from_numpy(fail)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).cuda()
+    mask = torch.from_numpy(sc["env_scope_mask"]).cuda()
+
+    def run(use_sinks):
+        st = GaussianTrainState({k: v.clone() for k, v in tensors.items()}, "cuda")
+
+        class Env:
+            params = {"Cubemap_texture": st.p["cubemap"], "Cubemap_failv": st.p["fail"]}
+        st.grads.zero_()
+        for i, cam in enumerate(cams):
+            ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+            rast = GaussianRasterizer(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                                                    bg=torch.zeros(3, device="cuda"), scale_modifier=1.0,
+                                                                    viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"], sh_degree=3,
+                                                                    campos=ct["campos"], prefiltered=False, debug=False))
+            rsink = None
+            if use_sinks:
+                rast.set_grad_sink(st.grads.sink(), accumulate=i > 0)
+                rsink = st.grads.sink(names=("cubemap", "fail"))
+            base, radii, allmap, refl_map, gw = rast(means3D=st.p["means3D"], means2D=torch.zeros(P, 3, device="cuda", requires_grad=True),
+                                                     opacities=st.p["opacities"], shs=st.p["shs"], refl_strengths=st.p["refl_strengths"],
+                                                     scales=st.p["scales"], rotations=st.p["rotations"], env_scope_mask=mask)
+            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, Env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"],
+                                              grad_sink=rsink, accumulate=i > 0)
+            photometric_loss(final, gt, 0.2).backward()
+        if use_sinks:
+            st.grads.all_reduce()
+        grads = st.grads.flat.clone()
+        st.update_learning_rate(1)
+        st.optimizer.step()
+        return grads, st.params.flat.clone()
+
+    g_plain, p_plain = run(False)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        g_sunk, p_sunk = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert torch.isfinite(g_sunk).all() and g_sunk.abs().max() > 0
+    den = g_plain.abs().max().item()
+    assert (g_sunk - g_plain).abs().max().item() <= 5e-5 * den
+    # identical gradients up to atomics order -> the Adam step (sign-like at step 1) lands within the learning rate
+    assert (p_sunk - p_plain).abs().max().item() <= 2.1 * 0.0025 + 1e-6
