@@ -167,10 +167,12 @@ ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int pla
 	if (total) *total = c.size();
 	return s;
 }
-BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total) {
+BinningState carve_binning(void* buf, size_t R, size_t tiles, size_t sort_bytes, size_t* total) {
 	Carver c(buf);
 	BinningState b;
 	b.point_list = c.take<uint32_t>(R);
+	b.mask_stride = R / 64 + tiles + 1;
+	b.blend_mask = c.take<unsigned long long>(4 * b.mask_stride);
 	b.tile_keys = c.take<uint32_t>(R);
 	b.tile_keys_unsorted = c.take<uint32_t>(R);
 	b.vals_unsorted = c.take<uint32_t>(R);
@@ -196,8 +198,11 @@ BinningState carve_binning(void* buf, size_t R, size_t sort_bytes, size_t* total
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
-                                                         uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes) {
+                                                         uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes,
+                                                         unsigned long long* __restrict__ blend_mask, size_t blend_words) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
+	// (the forward tile kernel only writes the blend masks of the batches it reaches: the rest must read as "nothing blended")
+	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * 256u) blend_mask[t] = 0ull;
 	// the tile ranges (tile_ranges_kernel fills the non-empty ones after the sort) and the look-back state of the tile-id
 	// sort that follows are cleared here: a dispatch of its own costs ~5 us whatever it does
 	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
@@ -379,10 +384,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	const int bit = (int)higher_msb(tiles);
 	const size_t sort_bytes = R > 0 ? sort_temp_bytes((size_t)R, bit) : 0;
 	size_t total = 0;
-	carve_binning(nullptr, (size_t)R, sort_bytes, &total);
+	carve_binning(nullptr, (size_t)R, (size_t)tiles, sort_bytes, &total);
 	void* buf = alloc(alloc_user, GSR_BUF_BINNING, total);
 	if (!buf && total > 0) { set_error("binning buffer allocation of %zu bytes failed", total); return GSR_E_ALLOC; }
-	BinningState b = carve_binning(buf, (size_t)R, sort_bytes, nullptr);
+	BinningState b = carve_binning(buf, (size_t)R, (size_t)tiles, sort_bytes, nullptr);
 	*out_binning = b;
 
 	if (R == 0) GSR_HIP_CHECK(hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream));   // otherwise emit_tiles_kernel clears them
@@ -391,7 +396,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
 		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
-		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes); }
+		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
+		                                                       4 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
@@ -514,7 +520,7 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	const int stride = rec_f4 * 4;
 	GeomState g = carve_geom((void*)geom_buffer, P, rec_f4, variant == 0 ? 0 : 6, variant == 0 ? 20 : 16, scan_temp_bytes(P), nullptr);
 	ImageState im = carve_image((void*)image_buffer, HW, tiles, variant == 0 ? 3 : 1, variant == 0 ? 2 : 1, nullptr);
-	BinningState b = carve_binning((void*)binning_buffer, R, 0, nullptr);
+	BinningState b = carve_binning((void*)binning_buffer, R, tiles, 0, nullptr);
 	auto d2d = [&](const void* src, size_t bytes) -> int {
 		if (bytes == 0) return 0;
 		GSR_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));

@@ -747,7 +747,7 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 	const int ntiles = tiles_x * tiles_y;
 	GeomState geom = carve_geom(geom_buffer, P, G_REC_F4, 6, G_ACC_F, scan_temp_bytes(P), nullptr);
 	ImageState img = carve_image(image_buffer, HW, ntiles, 1, 1, nullptr);
-	BinningState bin = carve_binning(binning_buffer, R, 0, nullptr);
+	BinningState bin = carve_binning(binning_buffer, R, ntiles, 0, nullptr);
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * G_ACC_F * sizeof(float), stream));
 	if (R > 0) {

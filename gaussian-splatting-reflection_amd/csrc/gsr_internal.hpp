@@ -89,6 +89,10 @@ struct ImageState {
 };
 struct BinningState {
 	uint32_t* point_list;        // R  Gaussian index of each instance, ordered by (tile, depth, index)   [first: the backward finds it without sizes]
+	unsigned long long* blend_mask;  // 4 x mask_stride: per (tile quadrant, batch of 64 list entries) the entries that blended into at least one
+	                                 // of the quadrant's pixels in the forward (written by the forward tile kernel, read by the backward one, which
+	                                 // then neither votes nor touches pairs that cannot contribute); batch b of tile t sits at range.x / 64 + t + b
+	size_t mask_stride;          // R / 64 + tiles + 1
 	uint32_t* tile_keys;         // R  tile id of each instance, sorted
 	uint32_t* tile_keys_unsorted;
 	uint32_t* vals_unsorted;
@@ -98,7 +102,7 @@ struct BinningState {
 
 GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_floats, size_t scan_temp_bytes, size_t* total);
 ImageState carve_image(void* buf, size_t HW, size_t tiles, int planes_T, int planes_n, size_t* total);
-BinningState carve_binning(void* buf, size_t R, size_t sort_temp_bytes, size_t* total);
+BinningState carve_binning(void* buf, size_t R, size_t tiles, size_t sort_temp_bytes, size_t* total);
 
 int option_cull();   // 1 (default): per-wave bounding-box culling in the tile kernels; 0: evaluate every list entry
 int option_dev();    // development ablation bits (0 in production): 1 = skip the gradient atomics of the surfel backward

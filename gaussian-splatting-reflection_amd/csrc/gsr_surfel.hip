@@ -339,7 +339,7 @@ struct SurfelFwdPix {
 // One (wave, surfel) pair of the forward.  `done` = lanes whose pixel has retired (or lies outside the image); returns the
 // lanes that blended (ok) and updates `done`.  wq receives the blend weight (0 where the pair did not contribute).
 __device__ __forceinline__ lmask surfel_fwd_pair(const SurfelRec& R, const v2f pix, uint32_t contributor, bool med_live, SurfelFwdPix& st,
-                                                 lmask& done, float& wq) {
+                                                 lmask& done, float& wq, bool& grazed) {
 	float sx, sy, rho3d, depth, alpha, rho2d;
 	{
 #pragma clang fp contract(off)
@@ -359,6 +359,7 @@ __device__ __forceinline__ lmask surfel_fwd_pair(const SurfelRec& R, const v2f p
 			sx = ppx * inv; sy = ppy * inv;
 			rho3d = sx * sx + sy * sy;
 		} else {                                      // some lane's ray grazes the splat plane: the reference's select form
+			grazed = true;                            // (the backward uses another threshold there: it must look at this pair itself)
 			const float inv = div_nr(1.0f, selm(unstable, 1.0f, pz));
 			sx = selm(unstable, 0.f, ppx * inv); sy = selm(unstable, 0.f, ppy * inv);
 			rho3d = selm(unstable, 1e8f, sx * sx + sy * sy);
@@ -409,7 +410,8 @@ __global__ void __launch_bounds__(64) GSR_FWD_ATTR
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                              float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights) {
+                              float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights,
+                              unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
@@ -436,6 +438,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 	st.Crg = st.Nxy = st.NzR = st.DM = mk2(0.f, 0.f);
 	st.last_contributor = 0;
 	bool med_live = true;
+	const size_t batch0 = (size_t)(range.x / S_WBATCH) + tile;     // where this tile's batches sit in blend_mask (see BinningState)
 	// (hit ordinal + value slot of this lane's quad) * 16 bytes + row * 4: where the lane parks a row maximum (row_max4)
 	const uint32_t wmax_off = (uint32_t)row_reduce_slot(lane) * 16u + (uint32_t)(lane >> 4) * 4u;
 
@@ -455,10 +458,10 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
 		s_wmax[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+		const int kown = __popcll(mm & ((1ull << lane) - 1ull));   // this lane's entry is hit number kown (if it is a hit)
 		if (hit) {
-			const int k = __popcll(mm & ((1ull << lane) - 1ull));
-			s_hid[k] = id;
-			s_hc[k] = (uint32_t)(base + lane + 1);     // the pair's contributor number (1-based position in the tile's list)
+			s_hid[kown] = id;
+			s_hc[kown] = (uint32_t)(base + lane + 1);  // the pair's contributor number (1-based position in the tile's list)
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
@@ -472,34 +475,36 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 			return Rec{q[0], q[1], q[2], q[3], q[4]};
 		};
 		Rec A = fetch(0), B = A;
+		unsigned long long force = 0ull;     // hits whose pair had a grazing lane (rare): the backward must evaluate them itself
 		for (int k = 0; k < nh; k += 4) {
 			float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
 			lmask any = 0ull;
-			bool stop;
+			bool stop, grazed = false;
 			{
 				const uint32_t c = __builtin_amdgcn_readlane(hc, k);
 				if (k + 1 < nh) B = fetch(k + 1);
-				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w0);
+				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w0, grazed);
 				stop = done == ~0ull || k + 1 >= nh;
 			}
 			if (!stop) {
 				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 1);
 				if (k + 2 < nh) A = fetch(k + 2);
-				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w1);
+				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w1, grazed);
 				stop = done == ~0ull || k + 2 >= nh;
 			}
 			if (!stop) {
 				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 2);
 				if (k + 3 < nh) B = fetch(k + 3);
-				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w2);
+				any |= surfel_fwd_pair(A, pix, c, med_live, st, done, w2, grazed);
 				stop = done == ~0ull || k + 3 >= nh;
 			}
 			if (!stop) {
 				const uint32_t c = __builtin_amdgcn_readlane(hc, k + 3);
 				if (k + 4 < nh) A = fetch(k + 4);
-				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w3);
+				any |= surfel_fwd_pair(B, pix, c, med_live, st, done, w3, grazed);
 				stop = done == ~0ull;
 			}
+			if (grazed) force |= 0xFull << k;    // (the whole group of four: which of them grazed is not worth tracking)
 			if (any != 0ull) {
 				// gaussian_weights (forward.cu:458-459): row maxima of the four weights; the rows are merged in step 3
 				const float z = row_max4(w0, w1, w2, w3);
@@ -509,13 +514,18 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 			if (stop) break;
 		}
 		__syncthreads();
-		// ---- 3. w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's
-		// check-then-atomicExch is racy, this is the true maximum
-		if (lane < nh) {
-			const float4 r = s_wmax[lane];
-			const float m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
-			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + hid, __float_as_int(m));
+		// ---- 3. per entry (each lane looks at ITS entry of the batch again): merge the four row maxima of its blend weight.
+		// w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's check-then-atomicExch is racy,
+		// this is the true maximum.  The entries that blended anywhere in this block form the batch's blend mask: the
+		// backward tile kernel walks exactly those (no vote, no pairs that cannot contribute).
+		float m = 0.f;
+		if (hit) {
+			const float4 r = s_wmax[kown];
+			m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
+			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + id, __float_as_int(m));
 		}
+		const lmask blended = LMASK(m > 0.f) | __ballot(hit && ((force >> kown) & 1ull) != 0ull);
+		if (lane == 0) blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)(base / S_WBATCH)] = blended;
 		__syncthreads();
 	}
 	if (inside) {
@@ -704,8 +714,8 @@ __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRe
 
 // Wave-per-quadrant backward.  One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a tile and
 // walks the tile's list back to front in batches of 64 entries:
-//   1. each lane takes one list entry, loads its cull record and votes (ballot) whether the surfel's footprint can
-//      reach this block and lies before the wave's last contributor -> compacted private work list;
+//   1. each lane takes one list entry and looks it up in the batch's blend mask (written by the forward: the entries that
+//      blended into this block) -> compacted private work list;
 //   2. the wave differentiates the survivors one at a time; the record of the current one is wave-uniform and arrives
 //      through the scalar memory path into SGPRs (two buffers ping-pong), nothing is staged in LDS;
 //   3. per contributing surfel the 19 gradient values are reduced over each 16-lane row with exchange-type DPP
@@ -719,7 +729,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
                               int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                               const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
-                              float* __restrict__ acc) {
+                              float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
@@ -752,27 +762,24 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	// where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register (row_reduce_slot)
 	const uint32_t slab_lane = (uint32_t)(lane >> 4) * S_ACC_F + (uint32_t)row_reduce_slot(lane);
 
-	// skip the batches that lie entirely beyond wave_last (list is walked back to front)
-	const int first = max(0, count - wave_last);
-	for (int base = (first / S_WBATCH) * S_WBATCH; base < count; base += S_WBATCH) {
-		const int nb = min(S_WBATCH, count - base);
-		// ---- 1. vote
-		bool hit = lane < nb && (count - 1 - (base + lane)) < wave_last;
-		uint32_t id = 0;
-		if (hit) {
-			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
-			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - CULL_PAD, qx1 + CULL_PAD, qy0 - CULL_PAD, qy1 + CULL_PAD);
-			}
-		}
+	// The tile's list is walked back to front in the forward's batches of 64 entries; the forward left, per batch, the mask of
+	// the entries that blended into this block (plus the rare grazing pairs): only those are differentiated.  No footprint
+	// vote and no cull-record traffic here, and no pair that cannot contribute.
+	const size_t batch0 = (size_t)(range.x / S_WBATCH) + tile;
+	for (int b = (min(wave_last, count) - 1) / S_WBATCH; b >= 0; b--) {
+		const unsigned long long bits = blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)b];
+		if (bits == 0ull) continue;
+		// ---- 1. lane l looks at batch slot 63 - l, so that ascending lanes are descending list positions
+		const int pos = b * S_WBATCH + (S_WBATCH - 1 - lane);
+		const bool hit = ((bits >> (S_WBATCH - 1 - lane)) & 1ull) != 0ull && pos < wave_last;
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
 		// ---- 2. compact: lane k ends up holding the id / contributor number of the k-th surviving entry
 		if (hit) {
 			const int k = __popcll(mm & ((1ull << lane) - 1ull));
-			s_hid[k] = id;
-			s_hc[k] = (uint32_t)(count - 1 - (base + lane));
+			s_hid[k] = point_list[range.x + (uint32_t)pos];
+			s_hc[k] = (uint32_t)pos;
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
@@ -838,9 +845,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD
 surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
                               const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                              const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc) {
+                              const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc,
+                              const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	surfel_render_bwd_wave_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
-	                            dL_depths, dL_drefl_map, acc);
+	                            dL_depths, dL_drefl_map, acc, blend_mask, mask_stride);
 }
 
 // quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
@@ -1067,7 +1075,7 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 	                                                         option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
-	                                                         out_refl_strength_map, gaussian_weights); }
+	                                                         out_refl_strength_map, gaussian_weights, bin.blend_mask, bin.mask_stride); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
 }
@@ -1095,7 +1103,7 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 	const int ntiles = tiles_x * tiles_y;
 	GeomState geom = carve_geom(geom_buffer, P, S_REC_F4, 0, S_ACC_F, scan_temp_bytes(P), nullptr);
 	ImageState img = carve_image(image_buffer, HW, ntiles, 3, 2, nullptr);
-	BinningState bin = carve_binning(binning_buffer, R, 0, nullptr);
+	BinningState bin = carve_binning(binning_buffer, R, ntiles, 0, nullptr);
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
 	if (R > 0) {
@@ -1103,7 +1111,7 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		auto kern = surfel_render_bwd_wave_kernel;
 		kern<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
-		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc); }
+		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc, bin.blend_mask, bin.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
