@@ -330,20 +330,28 @@ __global__ void __launch_bounds__(256) rebuild_keys_kernel(int L, const uint32_t
 	keys[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)__float_as_uint(depths[point_list[i]]);
 }
 
-// One pinned host word per host thread for the num_rendered readback (the reference does a blocking
-// 4-byte cudaMemcpy on the default stream, rasterizer_impl.cu:286).
-static int* pinned_word() {
-	static thread_local int* w = nullptr;
-	if (!w) {
-		if (hipHostMalloc((void**)&w, 64, hipHostMallocDefault) != hipSuccess) w = nullptr;
-	}
-	return w;
+// One pinned host word and one event per (host thread, device) for the num_rendered readback (the reference does a blocking
+// 4-byte cudaMemcpy on the default stream, rasterizer_impl.cu:286).  Keyed by the current device: an event created on one
+// device must not be recorded on another device's stream.
+struct Readback {
+	int* word = nullptr;
+	hipEvent_t done = nullptr;
+};
+static Readback* readback_slot() {
+	static thread_local Readback slots[64];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+	Readback& r = slots[dev];
+	if (!r.word && hipHostMalloc((void**)&r.word, 64, hipHostMallocDefault) != hipSuccess) { r.word = nullptr; return nullptr; }
+	if (!r.done && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) { r.done = nullptr; return nullptr; }
+	return &r;
 }
 
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom, const ImageState& img,
                 BinningState* out_binning, int prefiltered, int debug, hipStream_t stream) {
-	int* host = pinned_word();
-	if (!host) { set_error("hipHostMalloc for the num_rendered readback failed"); return GSR_E_HIP; }
+	Readback* rb = readback_slot();
+	if (!rb) { set_error("pinned word / event for the num_rendered readback could not be created"); return GSR_E_HIP; }
+	int* host = rb->word;
 	{
 		StageTimer st_(GSR_STAGE_SCAN, stream);
 		size_t tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));   // the scans' part
@@ -355,8 +363,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		if (prefiltered) GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));   // the trap flag is only ever set then
 	}
 	// the host waits on THIS point only, not on the level-1 work enqueued behind it
-	static thread_local hipEvent_t readback_done = nullptr;
-	if (!readback_done) GSR_HIP_CHECK(hipEventCreateWithFlags(&readback_done, hipEventDisableTiming));
+	hipEvent_t readback_done = rb->done;
 	GSR_HIP_CHECK(hipEventRecord(readback_done, stream));
 	{
 		// level 1 (independent of num_rendered, so it runs while the host waits for the read-back): depth order of the
@@ -379,6 +386,15 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	const int R = host[0];
 	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
 	if (R < 0) { set_error("num_rendered overflowed int32"); return GSR_E_INVALID; }
+	// (a total of 2^32 or more wraps the 32-bit scan silently; P * tiles bounds it from above, so it can only happen then)
+	if ((unsigned long long)P * (unsigned long long)tiles_x * (unsigned long long)tiles_y >= (1ull << 32)) {
+		unsigned long long total = 0;   // rare, huge configurations only: exact 64-bit total on the host
+		std::vector<uint32_t> tt((size_t)P);
+		GSR_HIP_CHECK(hipMemcpyAsync(tt.data(), geom.tiles_touched, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		GSR_HIP_CHECK(hipStreamSynchronize(stream));
+		for (uint32_t v : tt) total += v;
+		if (total != (unsigned long long)(uint32_t)R) { set_error("num_rendered = %llu does not fit 32 bits", total); return GSR_E_INVALID; }
+	}
 
 	const uint32_t tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
 	const int bit = (int)higher_msb(tiles);

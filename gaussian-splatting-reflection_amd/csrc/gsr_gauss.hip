@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(64)
 gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                              const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                             float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth) {
+                             float* __restrict__ out_normal, float* __restrict__ out_refl, float* __restrict__ out_invdepth,
+                             unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
@@ -231,6 +232,7 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	float T = 1.0f;
 	uint32_t last_contributor = 0;
 	float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, RS = 0, ID = 0;
+	const size_t batch0 = (size_t)(range.x / G_WBATCH) + tile;     // where this tile's batches sit in blend_mask (see BinningState)
 
 	for (int base = 0; base < count; base += G_WBATCH) {
 		if (done == ~0ull) break;
@@ -246,15 +248,16 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
+		const int kown = __popcll(mm & ((1ull << lane) - 1ull));   // this lane's entry is hit number kown (if it is a hit)
 		if (hit) {
-			const int k = __popcll(mm & ((1ull << lane) - 1ull));
-			s_hid[k] = id;
-			s_hj[k] = (uint32_t)lane;
+			s_hid[kown] = id;
+			s_hj[kown] = (uint32_t)lane;
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
 		const uint32_t hj = lane < nh ? s_hj[lane] : 0u;
 		__syncthreads();
+		unsigned long long blendk = 0ull;    // hits that blended into at least one pixel of the block
 		// two SGPR record buffers ping-pong so that the next record's s_load stays in flight for a whole pair
 		struct Rec { float4 r0, r1, r2, r3; };
 		auto fetch = [&](int k) -> Rec {
@@ -281,6 +284,7 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 				if (INVDEPTH) ID = fmaf(R.r3.y, w, ID);
 				T = selm(ok, test_T, T);
 				last_contributor = selmu(ok, contributor, last_contributor);
+				blendk |= 1ull << k;
 			}
 			return done == ~0ull;
 		};
@@ -290,6 +294,9 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			if (k + 1 >= nh) break;
 			if (blend(k + 1, B, [&]() { if (k + 2 < nh) A = fetch(k + 2); })) break;
 		}
+		// the batch's blend mask (bit = position in the batch): the backward tile kernel walks exactly these entries
+		const lmask blended = __ballot(hit && ((blendk >> kown) & 1ull) != 0ull);
+		if (lane == 0) blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)(base / G_WBATCH)] = blended;
 	}
 	if (inside) {
 		const size_t HW = (size_t)H * W;
@@ -317,7 +324,8 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
                              const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                              const float* __restrict__ dL_dnormal_map, const float* __restrict__ dL_drefl_map,
-                             const float* __restrict__ dL_invdepths, float* __restrict__ acc) {
+                             const float* __restrict__ dL_invdepths, float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask,
+                             size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
@@ -365,24 +373,21 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
 	if (wave_last == 0) return;
-	const int first = max(0, count - wave_last);
-	for (int base = (first / G_WBATCH) * G_WBATCH; base < count; base += G_WBATCH) {
-		const int nb = min(G_WBATCH, count - base);
-		bool hit = lane < nb && (count - 1 - (base + lane)) < wave_last;
-		uint32_t id = 0;
-		if (hit) {
-			id = point_list[range.y - 1 - (uint32_t)(base + lane)];
-			if (cull) {
-				hit = cull_hit(bbox[2 * id], bbox[2 * id + 1], qx0 - G_CULL_PAD, qx1 + G_CULL_PAD, qy0 - G_CULL_PAD, qy1 + G_CULL_PAD);
-			}
-		}
+	// back to front through the forward's batches; per batch the forward left the mask of the entries that blended into this
+	// block: only those are differentiated (no footprint vote, no cull-record traffic, no pair that cannot contribute)
+	const size_t batch0 = (size_t)(range.x / G_WBATCH) + tile;
+	for (int b = (min(wave_last, count) - 1) / G_WBATCH; b >= 0; b--) {
+		const unsigned long long bits = blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)b];
+		if (bits == 0ull) continue;
+		const int pos = b * G_WBATCH + (G_WBATCH - 1 - lane);      // lane l looks at batch slot 63 - l: ascending lanes = descending positions
+		const bool hit = ((bits >> (G_WBATCH - 1 - lane)) & 1ull) != 0ull && pos < wave_last;
 		const unsigned long long mm = __ballot(hit);
 		const int nh = __popcll(mm);
 		if (nh == 0) continue;
 		if (hit) {
 			const int k = __popcll(mm & ((1ull << lane) - 1ull));
-			s_hid[k] = id;
-			s_hj[k] = (uint32_t)lane;
+			s_hid[k] = point_list[range.x + (uint32_t)pos];
+			s_hj[k] = (uint32_t)pos;
 		}
 		__syncthreads();
 		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
@@ -394,7 +399,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			return Rec{q[0], q[1], q[2], q[3]};
 		};
 		auto differentiate = [&](int k, const Rec& R, auto&& prefetch_next) {
-			const int contributor = count - 1 - (base + (int)__builtin_amdgcn_readlane(hj, k));
+			const int contributor = (int)__builtin_amdgcn_readlane(hj, k);   // 0-based position in the tile's list
 			float dx, dy, Gp, alpha_p;
 			const lmask ok = gauss_pair(R.r0, R.r1.x, R.r1.y, pixx, pixy, dx, dy, Gp, alpha_p) & LMASK(contributor < last_contributor) & inside_m;
 			__builtin_amdgcn_sched_barrier(0);
@@ -713,11 +718,11 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 		if (out_invdepth)
 			gauss_render_fwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 			                                                              option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
-			                                                              out_refl_strength_map, out_invdepth);
+			                                                              out_refl_strength_map, out_invdepth, bin.blend_mask, bin.mask_stride);
 		else
 			gauss_render_fwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
 			                                                               option_cull(), background, img.final_T, img.n_contrib, out_color, out_normal_map,
-			                                                               out_refl_strength_map, nullptr);
+			                                                               out_refl_strength_map, nullptr, bin.blend_mask, bin.mask_stride);
 	}
 	GSR_LAUNCH_CHECK(debug, stream);
 	return R;
@@ -757,11 +762,11 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 			if (dL_invdepths)
 				gauss_render_bwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 				                                                              geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
-				                                                              dL_drefl_strength_map, dL_invdepths, geom.acc);
+				                                                              dL_drefl_strength_map, dL_invdepths, geom.acc, bin.blend_mask, bin.mask_stride);
 			else
 				gauss_render_bwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
 				                                                               geom.bbox, option_cull(), img.final_T, img.n_contrib, dL_dpix, dL_dnormal_map,
-				                                                               dL_drefl_strength_map, nullptr, geom.acc);
+				                                                               dL_drefl_strength_map, nullptr, geom.acc, bin.blend_mask, bin.mask_stride);
 		}
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
