@@ -11,6 +11,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include "gsr_sort.hpp"
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
@@ -104,12 +105,18 @@ struct TouchedInOrder {
 };
 // bytes of the P-sized temp region: the two scans share the first part, the depth pre-sort has the second one to itself
 // (its look-back state is cleared by the preprocess kernel, before the first scan runs)
+// tiles_touched widened to 64 bits: num_rendered is their sum, and a 32-bit sum would wrap silently at 2^32 instances
+struct Widen {
+	__host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
+};
 static size_t scan_part_bytes(size_t P) {
-	size_t a = 0, b = 0;
+	size_t a = 0, b = 0, c = 0;
 	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
-	return (std::max(a, b) + 255) & ~(size_t)255;
+	auto wide = rocprim::make_transform_iterator((const uint32_t*)nullptr, Widen{});
+	(void)rocprim::reduce(nullptr, c, wide, (unsigned long long*)nullptr, 0ull, P, rocprim::plus<unsigned long long>(), 0, false);
+	return (std::max(std::max(a, b), c) + 255) & ~(size_t)255;
 }
 // temp bytes: the larger of the two drivers' needs, so that the runtime switch (option_sort_driver) never changes a workspace size
 static size_t depth_sort_bytes(size_t P) {
@@ -354,11 +361,15 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	int* host = rb->word;
 	{
 		StageTimer st_(GSR_STAGE_SCAN, stream);
+		// num_rendered = sum of tiles_touched, reduced in 64 bits (the reference's 32-bit InclusiveSum, rasterizer_impl.cu:282,
+		// wraps silently at 2^32 instances; its per-Gaussian offsets are not needed here: the instances are emitted in depth
+		// order from the second scan below, and gsr_debug_fetch("point_offsets") computes them on demand)
 		size_t tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));   // the scans' part
-		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, geom.tiles_touched, geom.point_offsets, (size_t)P, rocprim::plus<uint32_t>(),
-		                                      stream, false));
+		unsigned long long* total = reinterpret_cast<unsigned long long*>(geom.flags + 2);
+		auto wide = rocprim::make_transform_iterator((const uint32_t*)geom.tiles_touched, Widen{});
+		GSR_HIP_CHECK(rocprim::reduce(geom.scan_temp, tmp, wide, total, 0ull, (size_t)P, rocprim::plus<unsigned long long>(), stream, false));
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
-		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.point_offsets + (P - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+		GSR_HIP_CHECK(hipMemcpyAsync(host + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		host[1] = 0;
 		if (prefiltered) GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));   // the trap flag is only ever set then
 	}
@@ -383,19 +394,11 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		                                      false));
 	}
 	GSR_HIP_CHECK(hipEventSynchronize(readback_done));
-	const int R = host[0];
+	unsigned long long total64;
+	memcpy(&total64, host + 2, sizeof(total64));
 	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
-	if (R < 0) { set_error("num_rendered overflowed int32"); return GSR_E_INVALID; }
-	// (a total of 2^32 or more wraps the 32-bit scan silently; P * tiles bounds it from above, so it can only happen then)
-	if ((unsigned long long)P * (unsigned long long)tiles_x * (unsigned long long)tiles_y >= (1ull << 32)) {
-		unsigned long long total = 0;   // rare, huge configurations only: exact 64-bit total on the host
-		std::vector<uint32_t> tt((size_t)P);
-		GSR_HIP_CHECK(hipMemcpyAsync(tt.data(), geom.tiles_touched, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		GSR_HIP_CHECK(hipStreamSynchronize(stream));
-		for (uint32_t v : tt) total += v;
-		if (total != (unsigned long long)(uint32_t)R) { set_error("num_rendered = %llu does not fit 32 bits", total); return GSR_E_INVALID; }
-	}
-
+	if (total64 > 0x7fffffffull) { set_error("num_rendered = %llu does not fit the int the API returns", total64); return GSR_E_INVALID; }
+	const int R = (int)total64;
 	const uint32_t tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
 	const int bit = (int)higher_msb(tiles);
 	const size_t sort_bytes = R > 0 ? sort_temp_bytes((size_t)R, bit) : 0;
@@ -553,7 +556,12 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	if (n == "means2D") return d2d(g.means2D, (size_t)P * 8);
 	if (n == "tiles_touched") return d2d(g.tiles_touched, (size_t)P * 4);
 	if (n == "cull") return d2d(g.bbox, (size_t)P * 32);   // two float4 per Gaussian (see cull_hit)
-	if (n == "point_offsets") return d2d(g.point_offsets, (size_t)P * 4);
+	if (n == "point_offsets") {   // not kept by the forward (it only needs the total): inclusive scan of tiles_touched on demand
+		if (P == 0) return 0;
+		size_t tmp = (size_t)(static_cast<char*>(g.depth_sort_temp) - static_cast<char*>(g.scan_temp));
+		GSR_HIP_CHECK(rocprim::inclusive_scan(g.scan_temp, tmp, g.tiles_touched, g.point_offsets, (size_t)P, rocprim::plus<uint32_t>(), stream, false));
+		return d2d(g.point_offsets, (size_t)P * 4);
+	}
 	if (n == "clamped") {
 		if (P == 0) return 0;
 		widen_clamped_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, g.clamped, (uint8_t*)dst);
