@@ -179,7 +179,7 @@ BinningState carve_binning(void* buf, size_t R, size_t tiles, size_t sort_bytes,
 	BinningState b;
 	b.point_list = c.take<uint32_t>(R);
 	b.mask_stride = R / 64 + tiles + 1;
-	b.blend_mask = c.take<unsigned long long>(4 * b.mask_stride);
+	b.blend_mask = c.take<unsigned long long>(16 * b.mask_stride);
 	b.tile_keys = c.take<uint32_t>(R);
 	b.tile_keys_unsorted = c.take<uint32_t>(R);
 	b.vals_unsorted = c.take<uint32_t>(R);
@@ -416,7 +416,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
 		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
-		                                                       4 * b.mask_stride); }
+		                                                       16 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only

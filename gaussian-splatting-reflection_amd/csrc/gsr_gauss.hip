@@ -213,7 +213,7 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
                              unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -328,7 +328,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
                              size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
@@ -372,6 +372,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	int wave_last = last_contributor;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+	wave_last = __builtin_amdgcn_readfirstlane(wave_last);   // (uniform after the butterfly; tells the compiler so)
 	if (wave_last == 0) return;
 	// back to front through the forward's batches; per batch the forward left the mask of the entries that blended into this
 	// block: only those are differentiated (no footprint vote, no cull-record traffic, no pair that cannot contribute)

@@ -89,9 +89,10 @@ struct ImageState {
 };
 struct BinningState {
 	uint32_t* point_list;        // R  Gaussian index of each instance, ordered by (tile, depth, index)   [first: the backward finds it without sizes]
-	unsigned long long* blend_mask;  // 4 x mask_stride: per (tile quadrant, batch of 64 list entries) the entries that blended into at least one
-	                                 // of the quadrant's pixels in the forward (written by the forward tile kernel, read by the backward one, which
-	                                 // then neither votes nor touches pairs that cannot contribute); batch b of tile t sits at range.x / 64 + t + b
+	unsigned long long* blend_mask;  // 16 x mask_stride words, written by the forward tile kernel and read by the backward one, which then neither votes
+	                                 // nor touches pairs that cannot contribute.  Batch b (64 list entries) of tile t is batch index range.x / 64 + t + b.
+	                                 // Variant S: [batch index][quadrant][4x4 sub-block] = the entries that blended into at least one pixel of that
+	                                 // sub-block; variant G: [quadrant][batch index] (first 4 x mask_stride words) per 8x8 quadrant.
 	size_t mask_stride;          // R / 64 + tiles + 1
 	uint32_t* tile_keys;         // R  tile id of each instance, sorted
 	uint32_t* tile_keys_unsorted;
@@ -237,6 +238,12 @@ __device__ __forceinline__ void quad_sum5(float* z) {
 __device__ __forceinline__ void quad_sum4(float* z) {
 #define GSR_Q4(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3)
 	asm volatile("s_nop 1\n\t" GSR_Q4("quad_perm:[2,3,0,1]") GSR_Q4("quad_perm:[1,0,3,2]") : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+}
+// v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (which __builtin_ctz leaves undefined)
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) {
+	uint32_t r;
+	asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
 }
 // which of the four values of a row_reduce4 call quad q of a row ends up with
 __device__ __forceinline__ int row_reduce_slot(int lane) {

@@ -318,6 +318,9 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // the 64-lane max for gaussian_weights is done for four pairs at a time (row_max4: 2 DPP per pair instead of 6 + 6 nops),
 // the env-scope plane is an accumulated weight, and the median bookkeeping stops once no pixel has T > 0.5.
 #define S_WBATCH 64
+// lane -> pixel inside the wave's 8x8 block: 16-lane row r is the 4x4 sub-block (r & 1, r >> 1), lanes inside it row-major
+__device__ __forceinline__ int sub_px(int lane) { return ((lane >> 4) & 1) * 4 + (lane & 3); }
+__device__ __forceinline__ int sub_py(int lane) { return (lane >> 5) * 4 + ((lane >> 2) & 3); }
 #define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
 #ifndef S_SUB
 #define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
@@ -416,12 +419,13 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
                               unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
 	if (bx0 >= W || by0 >= H) return;
-	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+	// a 16-lane row (the unit of the DPP reductions) is a 4x4 pixel sub-block: the backward walks one list per sub-block
+	const int px = bx0 + sub_px(lane), py = by0 + sub_py(lane);
 	const bool inside = px < W && py < H;
 	const v2f pix = mk2((float)px, (float)py);
 	const uint2 range = ranges[tile];
@@ -430,7 +434,7 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 
 	__shared__ uint32_t s_hid[S_WBATCH];
 	__shared__ uint32_t s_hc[S_WBATCH];
-	__shared__ float4 s_wmax[S_WBATCH];            // [hit][16-lane row]: row maxima of the blend weight
+	__shared__ float4 s_wmax[S_WBATCH];            // [hit][16-lane row = 4x4 sub-block]: row maxima of the blend weight
 
 	lmask done = ~LMASK(px < W) | ~LMASK(py < H);  // lanes outside the image never blend
 	SurfelFwdPix st;
@@ -518,16 +522,21 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		__syncthreads();
 		// ---- 3. per entry (each lane looks at ITS entry of the batch again): merge the four row maxima of its blend weight.
 		// w > 0 always, so the IEEE bit pattern orders like a signed int; the reference's check-then-atomicExch is racy,
-		// this is the true maximum.  The entries that blended anywhere in this block form the batch's blend mask: the
-		// backward tile kernel walks exactly those (no vote, no pairs that cannot contribute).
-		float m = 0.f;
+		// this is the true maximum.  The entries that blended anywhere in a 4x4 sub-block (its row maximum is > 0) form that
+		// sub-block's blend mask of the batch: the backward tile kernel walks exactly those (no vote, no pairs that cannot
+		// contribute).
+		float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 		if (hit) {
-			const float4 r = s_wmax[kown];
-			m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
+			r = s_wmax[kown];
+			const float m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
 			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + id, __float_as_int(m));
 		}
-		const lmask blended = LMASK(m > 0.f) | __ballot(hit && ((force >> kown) & 1ull) != 0ull);
-		if (lane == 0) blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)(base / S_WBATCH)] = blended;
+		const lmask forced = __ballot(hit && ((force >> kown) & 1ull) != 0ull);
+		const lmask b0 = LMASK(r.x > 0.f) | forced, b1 = LMASK(r.y > 0.f) | forced, b2 = LMASK(r.z > 0.f) | forced, b3 = LMASK(r.w > 0.f) | forced;
+		if (lane < 4) {
+			const lmask mine = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+			blend_mask[(batch0 + (size_t)(base / S_WBATCH)) * 16u + quad * 4u + (uint32_t)lane] = mine;
+		}
 		__syncthreads();
 	}
 	if (inside) {
@@ -611,6 +620,8 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 //   * the cross products dL_dk = l x dL_dp, dL_dl = dL_dp x k are formed on the pairs X = (k.x, l.x), Y, Z in their
 //     natural order, which yields the results SWAPPED, (-nl, nk) per component; the consumers index accordingly (no
 //     register shuffles).
+// EARLY: leave (with v untouched) when no lane contributes — worth a branch where the caller's list is a conservative vote.
+template <bool EARLY = true>
 __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRec& R, const v2f pix, int contributor, lmask inside_m, float* v) {
 	v2f X, Y, Z, d;
 	float sx, sy, rho3d, rho2d, depth, inv_pz;
@@ -644,7 +655,7 @@ __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRe
 	const float G = exp_neg(power);   // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by this backward
 	const float alpha_raw = fminf(0.99f, R.opac() * G);
 	const lmask ok = LMASK(!(depth < S_NEAR)) & LMASK(!(alpha_raw < 1.0f / 255.0f)) & LMASK(contributor < s.last_contributor) & inside_m;
-	if (ok == 0ull) return 0ull;
+	if (EARLY && ok == 0ull) return 0ull;
 	const float alpha = selm0(ok, alpha_raw);
 	const float c_d = selm(ok, depth, 1.0f);
 	// a rejected pair may carry inf/NaN in s (it overflows when the ray grazes the splat plane); 0 * that must stay 0.  G needs
@@ -734,12 +745,12 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
                               float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = tile_order[slot >> 2], quad = slot & 3u;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
 	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
 	const int lane = threadIdx.x;
 	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
 	if (bx0 >= W || by0 >= H) return;
-	const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+	const int px = bx0 + sub_px(lane), py = by0 + sub_py(lane);
 	const bool inside = px < W && py < H;
 	const lmask inside_m = LMASK(px < W) & LMASK(py < H);
 	const v2f pixv = mk2((float)px, (float)py);
@@ -747,7 +758,6 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	const int count = (int)(range.y - range.x);
 	const size_t HW = (size_t)H * W;
 	const size_t pix = (size_t)W * py + px;
-	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
 
 	__shared__ float4 s_slab[S_SUB * 4 * (S_ACC_F / 4)];   // [hit in sub-batch][16-lane row][20 floats]
 	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
@@ -760,6 +770,7 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	int wave_last = st.last_contributor;
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+	wave_last = __builtin_amdgcn_readfirstlane(wave_last);   // (uniform after the butterfly; tells the compiler so)
 	if (wave_last == 0) return;
 	// where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register (row_reduce_slot)
 	const uint32_t slab_lane = (uint32_t)(lane >> 4) * S_ACC_F + (uint32_t)row_reduce_slot(lane);
@@ -769,7 +780,8 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	// vote and no cull-record traffic here, and no pair that cannot contribute.
 	const size_t batch0 = (size_t)(range.x / S_WBATCH) + tile;
 	for (int b = (min(wave_last, count) - 1) / S_WBATCH; b >= 0; b--) {
-		const unsigned long long bits = blend_mask[(size_t)quad * mask_stride + batch0 + (size_t)b];
+		const unsigned long long* mp = blend_mask + ((batch0 + (size_t)b) * 16u + quad * 4u);
+		const unsigned long long bits = (mp[0] | mp[1]) | (mp[2] | mp[3]);
 		if (bits == 0ull) continue;
 		// ---- 1. lane l looks at batch slot 63 - l, so that ascending lanes are descending list positions
 		const int pos = b * S_WBATCH + (S_WBATCH - 1 - lane);
@@ -842,6 +854,160 @@ surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __
 	}
 }
 
+// Sub-block form of the backward: the wave still owns an 8x8 pixel block, but each of its four 16-lane rows is a 4x4 pixel
+// sub-block that walks ITS OWN list back to front — the forward left, per (sub-block, batch of 64 list entries), the mask of
+// the entries that blended into at least one of its 16 pixels.  In one iteration row r differentiates the next entry of
+// its mask; the four rows work on up to four different surfels.  Measured on the C3 scene (tests/blend_stats.py): a shared
+// 8x8 list needs 3.13 M wave iterations with 31 % of the lanes carrying a blending pixel; four row lists that advance
+// batch by batch need 2.29 M (the ideal for 4x4 sub-blocks is 1.80 M).  What it costs: the record differs per row, so it
+// lives in VGPRs — staged per batch through LDS by the lane that owns the entry and picked up with row-uniform
+// ds_read_b128 — and the in-row DPP reduction (row_reduce20) yields a total per (row, surfel).  A blended surfel touches 2.3
+// of the four rows on average, and sending every row total to memory on its own cost more than the shorter lists gained
+// (2.3x the float atomics: 0.99 ms against 0.93 ms for the shared list, 0.76 ms with the atomics switched off).  So the row
+// totals of a batch are parked in a slab of (row, entry) slots — slot = (entries of the rows before) + (iteration of the
+// row), plain stores, no two writers — and when the batch is done each entry's rows are added up and leave as ONE 80-byte
+// row of float atomics, as in the shared-list form.
+#define S_CAP 48      // slab slots = (sub-block, entry) pairs differentiated between two flushes; a batch with more is cut (rare)
+__device__ __forceinline__ void
+surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                            const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,
+                            const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
+                            const float* __restrict__ dL_drefl_map, float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask) {
+	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
+	if (slot >= (uint32_t)ntiles * 4u) return;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
+	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+	const int lane = threadIdx.x, row = lane >> 4;
+	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
+	if (bx0 >= W || by0 >= H) return;
+	const int px = bx0 + sub_px(lane), py = by0 + sub_py(lane);
+	const bool inside = px < W && py < H;
+	const lmask inside_m = LMASK(px < W) & LMASK(py < H);
+	const v2f pixv = mk2((float)px, (float)py);
+	const uint2 range = ranges[tile];
+	const int count = (int)(range.y - range.x);
+	const size_t HW = (size_t)H * W;
+	const size_t pix = (size_t)W * py + px;
+
+	__shared__ float s_slab[(S_CAP + 2) * S_ACC_F];     // [slot][20 floats]; slot S_CAP takes the stores of rows that have run out, slot S_CAP + 1 stays zero
+	__shared__ float4 s_rec[S_WBATCH * S_REC_F4];       // records of the batch's blended entries (indexed by position in the batch)
+	__shared__ uint32_t s_cw[S_WBATCH];                 // per entry of the chunk (compacted): the slab slot of each of the four rows, one byte each
+	__shared__ uint32_t s_cid[S_WBATCH];                // its surfel id
+
+	SurfelBwdPix st;
+	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
+	st.pixs = mk2(-pixv.y, pixv.x);
+	int wave_last = st.last_contributor;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
+	wave_last = __builtin_amdgcn_readfirstlane(wave_last);   // (uniform after the butterfly; tells the compiler so)
+	if (wave_last == 0) return;
+	if (lane < S_ACC_F) s_slab[(S_CAP + 1) * S_ACC_F + lane] = 0.f;
+	// byte offset inside a slab slot where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register
+	const uint32_t slab_lane = (uint32_t)row_reduce_slot(lane) * 4u;
+	const unsigned long long lt = (1ull << lane) - 1ull, gt = ~((2ull << lane) - 1ull);   // batch positions below / above this lane's
+	// the flush: lanes 0..59 = 3 entries x 20 floats per pass
+	const uint32_t fl_k = (uint32_t)lane / S_ACC_F, fl_d = (uint32_t)lane - fl_k * S_ACC_F;
+	const bool fl_on = lane < 3 * S_ACC_F && fl_d < S_ACC_F - 1;
+	float* const fl_acc = acc + fl_d;
+	const char* const slab_b = reinterpret_cast<const char*>(s_slab);
+
+	const size_t batch0 = (size_t)(range.x / S_WBATCH) + tile;
+	for (int b = (min(wave_last, count) - 1) / S_WBATCH; b >= 0; b--) {
+		const unsigned long long* mp = blend_mask + ((batch0 + (size_t)b) * 16u + quad * 4u);
+		const lmask m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3];
+		const lmask any = (m0 | m1) | (m2 | m3);
+		if (any == 0ull) continue;
+		// ---- 1. stage: lane l owns batch position l; if its entry blended anywhere in the block it fetches the record for the wave
+		uint32_t id = 0u;
+		if ((any >> lane) & 1ull) {
+			id = point_list[range.x + (uint32_t)(b * S_WBATCH + lane)];
+			const float4* q = rec + (size_t)id * S_REC_F4;
+			const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+			float4* d = s_rec + lane * S_REC_F4;
+			d[0] = r0; d[1] = r1; d[2] = r2; d[3] = r3; d[4] = r4;
+		}
+		// a row that has run out re-reads some staged record (finite values; all its lanes are masked off)
+		const uint32_t jany = 63u - (uint32_t)__builtin_clzll(any);
+		// ---- 2. chunks: normally the whole batch; a batch with more than S_CAP (row, entry) pairs is cut at multiples of 8 positions
+		lmask todo = any;
+		while (todo != 0ull) {
+			lmask c = ~0ull;
+			if (__popcll(m0 & todo) + __popcll(m1 & todo) + __popcll(m2 & todo) + __popcll(m3 & todo) > S_CAP) {
+				c = 0ull;
+#pragma unroll 1
+				for (int e = 7; e >= 0; e--) {          // from the top: the list is walked back to front
+					const lmask em = (0xFFull << (8 * e)) & todo;
+					if (em == 0ull) continue;
+					const lmask cc = c | em;
+					if (c != 0ull && __popcll(m0 & cc) + __popcll(m1 & cc) + __popcll(m2 & cc) + __popcll(m3 & cc) > S_CAP) break;
+					c = cc;
+				}
+			}
+			const lmask c0 = m0 & todo & c, c1 = m1 & todo & c, c2 = m2 & todo & c, c3 = m3 & todo & c, call = any & todo & c;
+			todo &= ~c;
+			const int n0 = __popcll(c0), n1 = __popcll(c1), n2 = __popcll(c2), n3 = __popcll(c3);
+			const int nmax = max(max(n0, n1), max(n2, n3));
+			const int nent = __popcll(call);
+			// slab slot of (row r, entry): the rows' slots are laid out one row after the other, in the order the row visits them;
+			// a row that skips the entry is pointed at the zero slot
+			if ((call >> lane) & 1ull) {
+				const uint32_t s0 = ((c0 >> lane) & 1ull) ? (uint32_t)__popcll(c0 & gt) : (uint32_t)(S_CAP + 1);
+				const uint32_t s1 = ((c1 >> lane) & 1ull) ? (uint32_t)(n0 + __popcll(c1 & gt)) : (uint32_t)(S_CAP + 1);
+				const uint32_t s2 = ((c2 >> lane) & 1ull) ? (uint32_t)(n0 + n1 + __popcll(c2 & gt)) : (uint32_t)(S_CAP + 1);
+				const uint32_t s3 = ((c3 >> lane) & 1ull) ? (uint32_t)(n0 + n1 + n2 + __popcll(c3 & gt)) : (uint32_t)(S_CAP + 1);
+				const int k = __popcll(call & lt);
+				s_cw[k] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+				s_cid[k] = id;
+			}
+			__syncthreads();
+			// ---- 3. differentiate: every row takes the LAST remaining entry of its own mask.  The mask is kept bit-reversed so that
+			// "last entry" is the lowest set bit (v_ffbl) and dropping it is x & (x - 1).
+			unsigned long long left = __builtin_bitreverse64(row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : c3)));
+			// byte offset of the row's next slab slot
+			uint32_t myslot = (uint32_t)(row == 0 ? 0 : (row == 1 ? n0 : (row == 2 ? n0 + n1 : n0 + n1 + n2))) * (S_ACC_F * 4u) + slab_lane;
+#pragma unroll 1
+			for (int t = 0; t < nmax; t++) {
+				const uint32_t lo = (uint32_t)left, hi = (uint32_t)(left >> 32);
+				const lmask valid = LMASK((lo | hi) != 0u);
+				const uint32_t tz = min(ffbl_raw(lo), ffbl_raw(hi) | 32u);   // count of trailing zeros; garbage if left == 0
+				const uint32_t j = selmu(valid, 63u - tz, jany);
+				left &= left - 1ull;
+				const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + ((j << 6) + (j << 4)));   // j * 80 B
+				const SurfelRec R{q[0], q[1], q[2], q[3], q[4]};
+				float v[S_ACC_F];
+				v[S_ACC_F - 1] = 0.f;
+				// (no early exit: the masks are exact, an entry without a blending lane is a rare forced one, and then v is all zeros)
+				surfel_bwd_pair<false>(st, R, pixv, b * S_WBATCH + (int)j, inside_m & valid, v);
+				// 20 values -> 5 registers of per-row totals; every lane of quad q of row r parks value slot(q) of each register
+				float z[5];
+				row_reduce20(v, z);
+				float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(s_slab) + selmu(valid, myslot, (uint32_t)(S_CAP * S_ACC_F * 4) + slab_lane));
+				myslot += S_ACC_F * 4u;
+#pragma unroll
+				for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
+			}
+			// ---- 4. flush: lane -> (entry of the chunk, float d), three entries per pass; the entry's rows are added up and leave as
+			// 80 contiguous bytes of float atomics per surfel
+			__syncthreads();
+#pragma unroll 1
+			for (int k0 = 0; k0 < nent; k0 += 3) {
+				const uint32_t k = (uint32_t)k0 + fl_k;
+				if (fl_on && k < (uint32_t)nent) {
+					const uint32_t w = s_cw[k], eid = s_cid[k];
+					const char* base = slab_b + fl_d * 4u;
+					const float a0 = *reinterpret_cast<const float*>(base + (w & 0xFFu) * (S_ACC_F * 4u));
+					const float a1 = *reinterpret_cast<const float*>(base + ((w >> 8) & 0xFFu) * (S_ACC_F * 4u));
+					const float a2 = *reinterpret_cast<const float*>(base + ((w >> 16) & 0xFFu) * (S_ACC_F * 4u));
+					const float a3 = *reinterpret_cast<const float*>(base + (w >> 24) * (S_ACC_F * 4u));
+					if (!(dev_flags & 1)) atomicAdd(fl_acc + (size_t)eid * S_ACC_F, (a0 + a1) + (a2 + a3));
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
 // 75 VGPRs.  Measured at C3 (balanced XCD mapping) with amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE, GSR_BWD_WPE)))
 surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
@@ -851,6 +1017,14 @@ surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
                               const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
 	surfel_render_bwd_wave_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
 	                            dL_depths, dL_drefl_map, acc, blend_mask, mask_stride);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE, GSR_BWD_WPE)))
+surfel_render_bwd_rows_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+                              const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,
+                              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
+                              const float* __restrict__ dL_drefl_map, float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask) {
+	surfel_render_bwd_rows_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, dev_flags, final_Ts, n_contrib, dL_dpixels, dL_depths,
+	                            dL_drefl_map, acc, blend_mask);
 }
 
 // quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
@@ -1111,9 +1285,14 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 	if (R > 0) {
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
-		auto kern = surfel_render_bwd_wave_kernel;
-		kern<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec, geom.bbox, option_cull(),
-		                                option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc, bin.blend_mask, bin.mask_stride); }
+		if (option_dev() & 4)   // dev A/B: the shared-list form
+			surfel_render_bwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                         geom.bbox, option_cull(), option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers,
+			                                                         dL_drefl_strength_map, geom.acc, bin.blend_mask, bin.mask_stride);
+		else
+			surfel_render_bwd_rows_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+			                                                         option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc,
+			                                                         bin.blend_mask); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);

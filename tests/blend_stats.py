@@ -92,6 +92,25 @@ for tile in range(gx * gy):
     pad = np.zeros((nb * 64 - n, 16), bool)
     sb = np.concatenate([s_any, pad]).reshape(nb, 64, 16).sum(1)          # batches x sub-blocks
     hb = np.concatenate([h_any, pad[:, :8]]).reshape(nb, 64, 8).sum(1)
+    sp = np.concatenate([s_any, pad])
+    for c in (32, 16, 8):
+        sc = sp.reshape(nb * (64 // c), c, 16).sum(1)
+        for q in range(4):
+            tot["chunk%d" % c] = tot.get("chunk%d" % c, 0) + int(sc[:, q * 4:q * 4 + 4].max(1).sum())
+    # adaptive chunks: consecutive entries of a batch while the (sub-block, entry) pairs of the quadrant fit CAP slab slots
+    for q in range(4):
+        sq = sp[:, q * 4:q * 4 + 4].reshape(nb, 64, 4)
+        for cap in (32, 48, 64):
+            it = 0
+            for bi in range(nb):
+                cnt = np.zeros(4, np.int64)
+                for e in range(64):
+                    row = sq[bi, e]
+                    if cnt.sum() + row.sum() > cap:
+                        it += int(cnt.max()); cnt[:] = 0
+                    cnt += row
+                it += int(cnt.max())
+            tot["cap%d" % cap] = tot.get("cap%d" % cap, 0) + it
     for q in range(4):
         rows = sb[:, q * 4:q * 4 + 4]
         tot["shared"] += int(s_any[:, q * 4:q * 4 + 4].any(1).sum())
@@ -110,6 +129,10 @@ print("  blending (pixel, entry) pairs      %10.2f M" % (tot["pix"] * s / 1e6))
 print("  shared 8x8 list                     %10.2f M iterations   (%.0f %% useful lanes)" % (tot["shared"] * s / 1e6, 100.0 * tot["pix"] / (64.0 * tot["shared"])))
 print("  4x4 sub-block pairs                 %10.2f M   -> ideal %.2f M iterations" % (tot["sub"] * s / 1e6, tot["sub"] * s / 4e6))
 print("  four 4x4 rows, coupled per batch    %10.2f M iterations" % (tot["coupled"] * s / 1e6))
+for c in (32, 16, 8):
+    print("  four 4x4 rows, coupled per %2d entries %9.2f M iterations" % (c, tot["chunk%d" % c] * s / 1e6))
+for c in (32, 48, 64):
+    print("  four 4x4 rows, chunks of <= %d pairs %9.2f M iterations" % (c, tot["cap%d" % c] * s / 1e6))
 print("  four 4x4 rows, free                 %10.2f M iterations" % (tot["free"] * s / 1e6))
 print("  four 8x2 strips, free               %10.2f M iterations" % (tot["strip_free"] * s / 1e6))
 print("  two 8x4 halves, coupled per batch   %10.2f M iterations" % (tot["half_coupled"] * s / 1e6))
