@@ -947,7 +947,7 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 			const lmask c0 = m0 & todo & c, c1 = m1 & todo & c, c2 = m2 & todo & c, c3 = m3 & todo & c, call = any & todo & c;
 			todo &= ~c;
 			const int n0 = __popcll(c0), n1 = __popcll(c1), n2 = __popcll(c2), n3 = __popcll(c3);
-			const int nmax = max(max(n0, n1), max(n2, n3));
+			const int nmax = __builtin_amdgcn_readfirstlane(max(max(n0, n1), max(n2, n3)));
 			const int nent = __popcll(call);
 			// slab slot of (row r, entry): the rows' slots are laid out one row after the other, in the order the row visits them;
 			// a row that skips the entry is pointed at the zero slot
@@ -973,7 +973,7 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 				const uint32_t tz = min(ffbl_raw(lo), ffbl_raw(hi) | 32u);   // count of trailing zeros; garbage if left == 0
 				const uint32_t j = selmu(valid, 63u - tz, jany);
 				left &= left - 1ull;
-				const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + ((j << 6) + (j << 4)));   // j * 80 B
+				const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + __umul24(j, S_REC_F4 * 16u));   // (24-bit multiply: full rate)
 				const SurfelRec R{q[0], q[1], q[2], q[3], q[4]};
 				float v[S_ACC_F];
 				v[S_ACC_F - 1] = 0.f;
