@@ -188,16 +188,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the timed region: exactly K steps between two barrier + synchronize brackets, nothing else on the stream (no events, no
+    # per-stage timers: every hipEventRecord costs a ~5-10 us bubble between two kernels, 0.1 ms per step when every stage has two)
     sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    # the same K steps again, instrumented: one event per step (percentiles) and the library's per-stage hipEvent timers
     _gsr.profile_enable(True)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
         step()
     marks[args.steps].record()
     sync_all()
-    dt = time.perf_counter() - t0
     stages = _gsr.profile_collect()
     _gsr.profile_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -240,14 +246,17 @@ def main():
             render(views[0], None, False)
         torch.cuda.synchronize()
         nf = max(5, args.steps)
-        fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(nf + 1)]
         t1 = time.perf_counter()
+        for i in range(nf):
+            render(views[0], None, False)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+        fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(nf + 1)]
         for i in range(nf):
             fmarks[i].record()
             render(views[0], None, False)
         fmarks[nf].record()
         torch.cuda.synchronize()
-        fwd_ms = (time.perf_counter() - t1) / nf * 1e3
         fwd_step_ms = [fmarks[i].elapsed_time(fmarks[i + 1]) for i in range(nf)]
 
     scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
@@ -300,6 +309,9 @@ def main():
             "step_ms": percentiles(step_ms),
             "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4), "forward_step_ms": percentiles(fwd_step_ms),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
+            "instrumented": "step_ms and stage_ms_per_view come from a second pass of the same K steps with one event per step and the library's "
+                            "per-stage hipEvent timers on (each event record costs a 5-10 us bubble between kernels); value / ms_per_step are the "
+                            "uninstrumented pass",
             "step_algorithmic_GBps": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roof,
         }
@@ -369,15 +381,18 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
     for i in range(args.warmup):
         full_step(i + 1)
     sync_all()
-    _gsr.profile_enable(True)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t2 = time.perf_counter()
     for i in range(args.steps):
-        marks[i].record()
         loss = full_step(args.warmup + i + 1)
-    marks[args.steps].record()
     sync_all()
     fdt = time.perf_counter() - t2
+    _gsr.profile_enable(True)       # instrumented repeat (see main)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for i in range(args.steps):
+        marks[i].record()
+        loss = full_step(args.warmup + args.steps + i + 1)
+    marks[args.steps].record()
+    sync_all()
     fstages = _gsr.profile_collect()
     _gsr.profile_enable(False)
     for view in views:
