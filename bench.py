@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary end-to-end (loss + Adam) timing")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 (5e6 Gaussians, variant G) object")
+    ap.add_argument("--sync-reflection-tail", action="store_true",
+                    help="keep the cubemap-gradient tail of the reflection backward on the main stream (default: side stream, joined by the all-reduce)")
     ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
     args = ap.parse_args()
 
@@ -161,14 +163,17 @@ def main():
                                                             scales=scene.p["scales"], rotations=scene.p["rotations"],
                                                             env_scope_mask=scene.mask)
         final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
-                                                     grad_sink=refl_sink, accumulate=accumulate)
+                                                     grad_sink=refl_sink, accumulate=accumulate,
+                                                     async_tail=refl_sink is not None and not args.sync_reflection_tail)
         if base.grad_fn is not None:
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
 
     # The backward kernels write their parameter gradients straight into the flat all-reduce buffer (gradient sinks): the first
     # view of a step overwrites it, every further view of this rank adds to it on the device (accumulate mode) — no zero-fill,
-    # no autograd accumulation passes.  Then ONE all-reduce, inside the step.
+    # no autograd accumulation passes.  Then ONE all-reduce, inside the step.  The part of the reflection backward that only
+    # produces the cubemap gradient runs on the library's side stream beside the rasterizer backward (async_tail);
+    # FlatGrads.all_reduce() makes the step's stream wait for it, so it is inside the timed region.
     def step_into(buf, reduce):
         sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
         for i, view in enumerate(views):
@@ -371,7 +376,7 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
                                                                 shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
                                                                 rotations=st.p["rotations"], env_scope_mask=mask)
             final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
-                                              grad_sink=frsink, accumulate=i > 0)
+                                              grad_sink=frsink, accumulate=i > 0, async_tail=not args.sync_reflection_tail)
             loss = photometric_loss(final, gt_image, 0.2)
             loss.backward()
         st.grads.all_reduce()

@@ -73,6 +73,10 @@ def _load():
     lib.gsr_deferred_reflection_backward.argtypes = [P, P, P, P, P, P, c_uint32, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]
     lib.gsr_deferred_reflection_backward_accum.restype = c_int
     lib.gsr_deferred_reflection_backward_accum.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, P]
+    lib.gsr_deferred_reflection_backward_ex.restype = c_int
+    lib.gsr_deferred_reflection_backward_ex.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P]
+    lib.gsr_side_join.restype = c_int
+    lib.gsr_side_join.argtypes = [P]
     lib.gsr_normal_world_forward.restype = c_int
     lib.gsr_normal_world_forward.argtypes = [P, P, c_int, c_int, P, P]
     lib.gsr_normal_world_backward.restype = c_int
@@ -136,7 +140,7 @@ def compiled_binding():
 PYBIND = compiled_binding()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
-            "gsr_deferred_reflection_backward_accum", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
+            "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
             "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
@@ -147,6 +151,27 @@ STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "re
 
 def set_option(name, value):
     check(lib.gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")
+
+
+_side_held = []
+
+
+def side_hold(*tensors):
+    """Keeps device tensors alive that work on the library's side stream still reads (see side_join)."""
+    _side_held.extend(tensors)
+
+
+def side_join(device=None):
+    """Makes the current stream of `device` wait for everything the library has put on its side stream (the texel-gradient tail
+    of deferred_reflection(..., async_tail=True)), then lets go of the scratch tensors held for it.  No host synchronisation.
+    Call before anything reads the cubemap / fail-value gradient sink: gsr_dist.FlatGrads and gsr_train.FlatAdam do."""
+    import torch
+    if not _side_held:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        check(lib.gsr_side_join(torch.cuda.current_stream(dev).cuda_stream), "gsr_side_join")
+    _side_held.clear()
 
 
 def profile_enable(on=True):

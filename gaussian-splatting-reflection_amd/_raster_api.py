@@ -37,9 +37,10 @@ class GradSink:
     (accumulate=False) or adds (accumulate=True) those gradients straight into them and autograd receives None for the
     corresponding inputs: no zero-fill, no `grad += new` pass.  Not a tensor, so autograd passes it through untouched."""
 
-    def __init__(self, tensors, accumulate=False):
+    def __init__(self, tensors, accumulate=False, async_tail=False):
         self.tensors = dict(tensors)
         self.accumulate = bool(accumulate)
+        self.async_tail = bool(async_tail)     # deferred_reflection only: see its docstring
 
 
 @dataclass

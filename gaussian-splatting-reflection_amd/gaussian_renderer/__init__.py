@@ -132,24 +132,37 @@ class _DeferredReflection(torch.autograd.Function):
         g_fail = torch.empty_like(fv) if g_fail is None else g_fail
         n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=cm.device)
+        async_tail = ctx.sink is not None and ctx.sink.async_tail
+        if async_tail and not (sunk_cm and sunk_fail):
+            raise ValueError("reflection grad sink: async_tail=True needs both 'cubemap' and 'fail' tensors")
         with torch.cuda.device(nv.device):
-            check(lib.gsr_deferred_reflection_backward_accum(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
-                                                             ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
-                                                             ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
-                                                             stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+            check(lib.gsr_deferred_reflection_backward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
+                                                          ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
+                                                          ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
+                                                          int(async_tail), stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+        if async_tail:
+            _gsr.side_hold(scratch, g_cm, g_fail)     # read / written on the side stream until side_join()
         return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None, None
 
 
 def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, world_view_transform, HWK, R, T, grad_sink=None,
-                        accumulate=False):
+                        accumulate=False, async_tail=False):
     """Fused pixel pass.  normal_view = allmap[2:5] (view space, un-normalised).  Returns
     (final_image[3,H,W], refl_color[3,H,W], render_normal_world[3,H,W] normalised).
 
     grad_sink (extension, the counterpart of GaussianRasterizer.set_grad_sink): {"cubemap": float32 [6,3,L,L],
     "fail": float32 [3]} — e.g. views of gsr_dist.FlatGrads.  The backward of THIS call then writes (accumulate=False) or
-    adds (accumulate=True) the cubemap / fail-value gradient into them and returns None to autograd."""
+    adds (accumulate=True) the cubemap / fail-value gradient into them and returns None to autograd.
+
+    async_tail (with a grad_sink only): the part of the backward that produces the cubemap / fail-value gradient (sort of the
+    per-pixel footprint records, run combine, unpack — it feeds nothing but the sink) is enqueued on the library's side stream
+    and overlaps the rasterizer backward; the per-pixel gradients autograd receives are in stream order as always.  The
+    sink tensors are complete only after _gsr.side_join() — gsr_dist.FlatGrads.all_reduce / all_reduce_async / zero_ and
+    gsr_train.FlatAdam.step call it; code that reads the sink itself must too."""
+    if async_tail and not grad_sink:
+        raise ValueError("deferred_reflection: async_tail=True needs a grad_sink (autograd would read the gradient at once)")
     cam = _cam_block(world_view_transform, HWK, R, T)
-    sink = GradSink(grad_sink, accumulate) if grad_sink else None
+    sink = GradSink(grad_sink, accumulate, async_tail) if grad_sink else None
     return _DeferredReflection.apply(normal_view, base_color, refl_strength_map, env_map.params['Cubemap_texture'],
                                      env_map.params['Cubemap_failv'], cam, sink)
 
@@ -244,8 +257,10 @@ def _precomputed_transmats(viewpoint_camera, pc, scaling_modifier, dev):
 
 def _sinks(pipe):
     """Optional gradient sinks carried by the pipeline object (extension): pipe.gsr_grad_sink for the rasterizer,
-    pipe.gsr_reflection_grad_sink for the fused reflection op, pipe.gsr_accumulate for accumulate mode."""
-    return getattr(pipe, "gsr_grad_sink", None), getattr(pipe, "gsr_reflection_grad_sink", None), bool(getattr(pipe, "gsr_accumulate", False))
+    pipe.gsr_reflection_grad_sink for the fused reflection op, pipe.gsr_accumulate for accumulate mode,
+    pipe.gsr_async_reflection_tail for deferred_reflection's async_tail."""
+    return (getattr(pipe, "gsr_grad_sink", None), getattr(pipe, "gsr_reflection_grad_sink", None), bool(getattr(pipe, "gsr_accumulate", False)),
+            bool(getattr(pipe, "gsr_async_reflection_tail", False)))
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, initial_stage=False,
@@ -259,7 +274,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         means2D.retain_grad()
     except Exception:
         pass
-    raster_sink, refl_sink, accumulate = _sinks(pipe)
+    raster_sink, refl_sink, accumulate, async_tail = _sinks(pipe)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
     rasterizer.set_grad_sink(raster_sink, accumulate)
     if env_scope_radius > 0.0:
@@ -288,7 +303,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         return out
     final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
                                                                v.world_view_transform, v.HWK, v.R, v.T, grad_sink=refl_sink,
-                                                               accumulate=accumulate)
+                                                               accumulate=accumulate, async_tail=async_tail and bool(refl_sink))
     out.update({"rend_normal": rend_normal, "render": final_image, "refl_strength_map": refl_strength_map, "refl_color_map": refl_color,
                 "base_color_map": base_color})
     return out

@@ -62,7 +62,15 @@ class FlatGrads:
         other.flat = torch.zeros_like(self.flat)
         return other
 
+    def _join(self):
+        """Work the HIP library still has on its side stream for this buffer (deferred_reflection(async_tail=True)) is ordered
+        before whatever the current stream does next."""
+        if self.flat.is_cuda:
+            import _gsr
+            _gsr.side_join(self.flat.device)
+
     def zero_(self):
+        self._join()
         self.flat.zero_()
 
     def sink(self, names=("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths")):
@@ -83,6 +91,7 @@ class FlatGrads:
 
     def all_reduce(self, group=None, average=False):
         """Sum (or mean) of the per-rank gradients, in place.  No-op without an initialised process group."""
+        self._join()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
@@ -93,6 +102,7 @@ class FlatGrads:
         """Start the sum of the per-rank gradients and return the work handle (None without a process group of more than
         one rank).  `handle.wait()` makes the CURRENT STREAM wait for the result (no host block with RCCL); until then
         nothing may write this buffer."""
+        self._join()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         return None

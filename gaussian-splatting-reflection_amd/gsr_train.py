@@ -15,6 +15,7 @@ import math
 
 import torch
 
+import _gsr
 from _gsr import AdamSegment, check, lib, stream_ptr
 from gsr_dist import FlatGrads
 
@@ -103,6 +104,7 @@ class FlatAdam:
         self.step_count += 1
         segs = self._segments()
         dev = self.params.flat.device
+        _gsr.side_join(dev)      # (the cubemap gradient may still be in flight on the library's side stream)
         with torch.cuda.device(dev):
             check(lib.gsr_adam_step(self.params.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                     self.params.total, segs, len(segs), self.betas[0], self.betas[1], self.eps, self.step_count,

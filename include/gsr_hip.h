@@ -184,6 +184,20 @@ int gsr_deferred_reflection_backward_accum(const float* normal_view, const float
                                      const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
                                      float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
                                      int accumulate, void* stream);
+/* Extension: async_tail != 0 (sorted path only) enqueues the part of the backward that produces g_cubemap / g_fail — sort of
+ * the footprint records, run combine, unpack; nothing else in a training step depends on it before the optimizer — on a
+ * low-priority side stream owned by the library (one per device) that forks from `stream` after the pixel kernel, so that
+ * it runs beside whatever the caller enqueues next on `stream` (the rasterizer backward).  g_normal_view / g_base /
+ * g_strength are complete in `stream` order as always.  g_cubemap, g_fail and scratch must stay untouched and alive until
+ * gsr_side_join(s) has been called: it makes stream s wait (device-side, no host block) for all side work enqueued so far
+ * on the current device.  Successive tails are ordered among themselves (accumulate over a batch of views works). */
+int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
+                                        const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
+                                        int width, int height, const float* g_final, const float* g_refl_color,
+                                        const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
+                                        float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
+                                        int accumulate, int async_tail, void* stream);
+int gsr_side_join(void* stream);
 /* Shading normal alone: out = normalize(normal_view rotated to world space) with the reference's +1e-6
  * (gaussian_renderer/__init__.py:148,178-179), for the initial stage where render() skips the reflection chain but still
  * returns rend_normal; `cam` as above (only its first nine floats are read).  The backward writes g_normal_view fully. */

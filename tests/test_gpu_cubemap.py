@@ -274,3 +274,51 @@ def test_reflection_grad_sink_routes_cubemap_gradients():
     np.testing.assert_allclose(acc["fail"].cpu().numpy(), 1.5 * fail_p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         run({"cubemap": acc["cubemap"]}, accumulate=True)
+
+
+def test_reflection_async_tail_joined_before_the_sink_is_read():
+    """Extension: async_tail=True puts the cubemap-gradient part of the backward on the library's side stream.  The per-pixel
+    gradients autograd receives are unaffected; the sink is complete after _gsr.side_join() — overwrite and accumulate over
+    two backwards, a busy main stream in between — and FlatGrads.all_reduce() joins by itself."""
+    import _gsr
+    from gaussian_renderer import deferred_reflection
+    from gsr_dist import FlatGrads
+    W, H, L = 640, 360, 32
+    cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    g = torch.Generator().manual_seed(5)
+    nv0 = (torch.randn(3, H, W, generator=g) * torch.rand(1, H, W, generator=g)).cuda()
+    base, strength = torch.rand(3, H, W, generator=g).cuda(), torch.rand(1, H, W, generator=g).cuda()
+    tex0, fail0 = S.make_cubemap(L, 3, 6)
+    wf = torch.randn(3, H, W, generator=g).cuda()
+
+    class Env:
+        pass
+
+    def run(sink, accumulate=False, async_tail=False, scale=1.0):
+        tex = torch.from_numpy(tex0).cuda().requires_grad_(True)
+        fail = torch.from_numpy(fail0).cuda().requires_grad_(True)
+        nv = nv0.clone().requires_grad_(True)
+        env = Env()
+        env.params = {"Cubemap_texture": tex, "Cubemap_failv": fail}
+        f, _, _ = deferred_reflection(nv, base, strength, env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"], grad_sink=sink,
+                                      accumulate=accumulate, async_tail=async_tail)
+        (f * wf * scale).sum().backward()
+        return tex, fail, nv
+    tex_p, fail_p, nv_p = run(None)
+    with pytest.raises(ValueError):
+        run(None, async_tail=True)          # autograd would read the gradient at once
+    params = {"cubemap": torch.from_numpy(tex0).cuda().requires_grad_(True), "fail": torch.from_numpy(fail0).cuda().requires_grad_(True)}
+    fg = FlatGrads(params)
+    fg.flat.fill_(float("nan"))
+    sink = fg.sink(names=("cubemap", "fail"))
+    _, _, nv_a = run(sink, async_tail=True)
+    busy = torch.randn(2048, 2048, device="cuda")
+    busy = busy @ busy                       # main-stream work enqueued while the tail runs beside it
+    _, _, nv_b = run(sink, accumulate=True, async_tail=True, scale=0.5)
+    assert torch.equal(nv_a.grad, nv_p.grad) and rel_maxnorm(nv_b.grad.cpu().numpy(), 0.5 * nv_p.grad.cpu().numpy()) <= 1e-6
+    assert len(_gsr._side_held) > 0
+    fg.all_reduce()                          # joins (world size 1: nothing else)
+    assert len(_gsr._side_held) == 0
+    assert rel_maxnorm(fg.view("cubemap").cpu().numpy(), 1.5 * tex_p.grad.cpu().numpy()) <= 1e-5
+    np.testing.assert_allclose(fg.view("fail").cpu().numpy(), 1.5 * fail_p.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
