@@ -287,8 +287,8 @@ def main():
         fwd_bytes = 347 * P + 257 * R + 68 * HW     # SURVEY.md §8d, variant S
         bwdall_bytes = 871 * P + 156 * R + 64 * HW
         refl_bytes = (64 + 112) * HW
-        pmc = pmc_summary("surfel_render_bwd_wave_kernel", P, W, H)
-        roof = {"kernel": "surfel_render_bwd_wave_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        pmc = pmc_summary("surfel_render_bwd_rows_kernel", P, W, H)
+        roof = {"kernel": "surfel_render_bwd_rows_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"),
                 "traffic_source": pmc.get("source"), "avg_launch_ms": round(launch_s * 1e3, 4), "algorithmic_bytes_per_launch": bytes_bwd}
         if pmc.get("insts_valu"):

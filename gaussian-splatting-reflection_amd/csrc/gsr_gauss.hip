@@ -314,10 +314,20 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	}
 }
 
-// renderCUDA backward (DGR backward.cu:452-690), wave-per-quadrant form.  The reference issues 16 float
-// atomicAdds per contributing (pixel, Gaussian) pair; here the wave reduces the 16 values over each 16-lane row with
-// exchange-type DPP (row_reduce_groups), parks the four row totals in LDS and flushes their sum as one 64-byte row of
-// atomics per touched Gaussian into acc[P][16] (see surfel_render_bwd_wave_body for the full description).
+// renderCUDA backward (DGR backward.cu:452-690), wave-per-quadrant form, shared list.  One 64-thread workgroup (= one wave)
+// owns an 8x8 pixel block of a tile and walks the tile's list back to front in the forward's batches of 64 entries:
+//   1. each lane takes one list entry and looks it up in the batch's blend mask (written by the forward: the entries that
+//      blended into this block) -> ballot-compacted private work list: no footprint vote, no pair that cannot contribute;
+//   2. the wave differentiates the survivors one at a time; the record of the current one is wave-uniform and arrives
+//      through the scalar memory path into SGPRs (two buffers ping-pong), nothing is staged in LDS;
+//   3. per contributing Gaussian the 16 gradient values (the reference: 16 float atomicAdds per (pixel, Gaussian) pair) are
+//      reduced over each 16-lane row with exchange-type DPP (row_reduce16) and parked in the slab row of (hit, row);
+//   4. every G_SUB hits the wave adds the four row totals and flushes them as one 64-byte row of float atomics per
+//      Gaussian into acc[P][16].
+// No workgroup barriers and no waiting for sibling quadrants (the reference synchronises the 256 threads of a tile twice
+// per batch).  Variant S moved on to one list per 4x4 sub-block (surfel_render_bwd_rows_kernel); for this variant's much
+// cheaper pair that form was measured and did not pay: the per-row blend masks cost the forward more than the shorter
+// lists gave the backward (1 M Gaussians: fwd 0.265 -> 0.311 ms, bwd 0.534 -> 0.511 ms; 5 M: 0.44 -> 0.53, 0.84 -> 0.74).
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
 gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
@@ -447,7 +457,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			v[GA_CONIC + 2] = hg * gdy * dy;
 			v[GA_OPAC] = G * dL_dalpha;
 			// 16 values -> 4 registers of row totals (exchange-type DPP, see row_reduce_groups); the four 16-lane rows park
-			// theirs in separate slab rows and the flush adds them (as in surfel_render_bwd_wave_kernel)
+			// theirs in separate slab rows and the flush adds them
 			// (the four lanes of a quad hold the same totals and store them to the same address: cheaper than masking three off)
 			float z[4];
 			row_reduce16(v, z);

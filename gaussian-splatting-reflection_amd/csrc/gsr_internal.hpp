@@ -239,6 +239,9 @@ __device__ __forceinline__ void quad_sum4(float* z) {
 #define GSR_Q4(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3)
 	asm volatile("s_nop 1\n\t" GSR_Q4("quad_perm:[2,3,0,1]") GSR_Q4("quad_perm:[1,0,3,2]") : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
 }
+// lane -> pixel inside the wave's 8x8 block: 16-lane row r is the 4x4 sub-block (r & 1, r >> 1), lanes inside it row-major
+__device__ __forceinline__ int sub_px(int lane) { return ((lane >> 4) & 1) * 4 + (lane & 3); }
+__device__ __forceinline__ int sub_py(int lane) { return (lane >> 5) * 4 + ((lane >> 2) & 3); }
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (which __builtin_ctz leaves undefined)
 __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) {
 	uint32_t r;

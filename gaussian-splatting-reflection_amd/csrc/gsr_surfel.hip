@@ -318,13 +318,7 @@ __device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, floa
 // the 64-lane max for gaussian_weights is done for four pairs at a time (row_max4: 2 DPP per pair instead of 6 + 6 nops),
 // the env-scope plane is an accumulated weight, and the median bookkeeping stops once no pixel has T > 0.5.
 #define S_WBATCH 64
-// lane -> pixel inside the wave's 8x8 block: 16-lane row r is the 4x4 sub-block (r & 1, r >> 1), lanes inside it row-major
-__device__ __forceinline__ int sub_px(int lane) { return ((lane >> 4) & 1) * 4 + (lane & 3); }
-__device__ __forceinline__ int sub_py(int lane) { return (lane >> 5) * 4 + ((lane >> 2) & 3); }
 #define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
-#ifndef S_SUB
-#define S_SUB 16      // hits between two flushes of the backward's gradient slab (power of two)
-#endif
 #ifndef GSR_BWD_WPE
 #define GSR_BWD_WPE 4
 #endif
@@ -605,10 +599,11 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 	s.A = s.Dprev = s.last_alpha = 0.f;
 	s.bg_dot_dpixel = bg[0] * s.dp01.x + bg[1] * s.dp01.y + bg[2] * s.dp2;
 }
-// One (wave, surfel) pair of the back-to-front recursion (DSR backward.cu:292-467): ray-splat intersection with the
-// backward's `unstable` threshold (1e-6; the forward uses 1e-4 — a quirk of the reference, reproduced), then the per-pixel
-// state advance and the 19 gradient contributions (slots SA_*) into v.  Returns the lanes that contribute (0: nothing was
-// written).  Straight-line for all 64 lanes, predicates as lane masks (see surfel_fwd_pair):
+// One iteration of the back-to-front recursion (DSR backward.cu:292-467) — each lane against the surfel R of ITS 16-lane row:
+// ray-splat intersection with the backward's `unstable` threshold (1e-6; the forward uses 1e-4 — a quirk of the reference,
+// reproduced), then the per-pixel state advance and the 19 gradient contributions (slots SA_*) into v.  Returns the lanes
+// that contribute.  Straight-line for all 64 lanes and no early exit (the caller's lists are exact: an iteration without a
+// contributing lane is a rare forced entry, and then v is all zeros), predicates as lane masks (see surfel_fwd_pair):
 //   * a lane whose pair does not contribute runs with alpha = 0, which is the identity of every recurrence below
 //     (T/(1-0), blend weights 0), and has its two root gradients zeroed, so all of v comes out 0 without exec-mask regions
 //     or a zero-fill of v; depth and s are sanitised there too (they multiply those zeros and feed the recurrences);
@@ -620,8 +615,6 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 //   * the cross products dL_dk = l x dL_dp, dL_dl = dL_dp x k are formed on the pairs X = (k.x, l.x), Y, Z in their
 //     natural order, which yields the results SWAPPED, (-nl, nk) per component; the consumers index accordingly (no
 //     register shuffles).
-// EARLY: leave (with v untouched) when no lane contributes — worth a branch where the caller's list is a conservative vote.
-template <bool EARLY = true>
 __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRec& R, const v2f pix, int contributor, lmask inside_m, float* v) {
 	v2f X, Y, Z, d;
 	float sx, sy, rho3d, rho2d, depth, inv_pz;
@@ -655,7 +648,6 @@ __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRe
 	const float G = exp_neg(power);   // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by this backward
 	const float alpha_raw = fminf(0.99f, R.opac() * G);
 	const lmask ok = LMASK(!(depth < S_NEAR)) & LMASK(!(alpha_raw < 1.0f / 255.0f)) & LMASK(contributor < s.last_contributor) & inside_m;
-	if (EARLY && ok == 0ull) return 0ull;
 	const float alpha = selm0(ok, alpha_raw);
 	const float c_d = selm(ok, depth, 1.0f);
 	// a rejected pair may carry inf/NaN in s (it overflows when the ray grazes the splat plane); 0 * that must stay 0.  G needs
@@ -723,135 +715,6 @@ __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRe
 	v[SA_MEAN2D + 1] = gm.y;
 	v[SA_OPAC] = G * dL_dalpha;
 	return ok;
-}
-
-// Wave-per-quadrant backward.  One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a tile and
-// walks the tile's list back to front in batches of 64 entries:
-//   1. each lane takes one list entry and looks it up in the batch's blend mask (written by the forward: the entries that
-//      blended into this block) -> compacted private work list;
-//   2. the wave differentiates the survivors one at a time; the record of the current one is wave-uniform and arrives
-//      through the scalar memory path into SGPRs (two buffers ping-pong), nothing is staged in LDS;
-//   3. per contributing surfel the 19 gradient values are reduced over each 16-lane row with exchange-type DPP
-//      (row_reduce20) and parked in the slab row of (hit, row);
-//   4. every S_SUB hits the wave adds the four row totals and flushes them as 80 contiguous bytes of float atomics per
-//      surfel into acc[P][20].
-// No workgroup barriers and no waiting for sibling quadrants (the reference design synchronises the 256
-// threads of a tile twice per batch).  The reference issues ~19 atomics per (pixel, surfel) pair.
-__device__ __forceinline__ void
-surfel_render_bwd_wave_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull,
-                              int dev_flags, const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-                              const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map,
-                              float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
-	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
-	if (slot >= (uint32_t)ntiles * 4u) return;
-	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
-	const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-	const int lane = threadIdx.x;
-	const int bx0 = tile_x * 16 + (quad & 1) * 8, by0 = tile_y * 16 + (quad >> 1) * 8;
-	if (bx0 >= W || by0 >= H) return;
-	const int px = bx0 + sub_px(lane), py = by0 + sub_py(lane);
-	const bool inside = px < W && py < H;
-	const lmask inside_m = LMASK(px < W) & LMASK(py < H);
-	const v2f pixv = mk2((float)px, (float)py);
-	const uint2 range = ranges[tile];
-	const int count = (int)(range.y - range.x);
-	const size_t HW = (size_t)H * W;
-	const size_t pix = (size_t)W * py + px;
-
-	__shared__ float4 s_slab[S_SUB * 4 * (S_ACC_F / 4)];   // [hit in sub-batch][16-lane row][20 floats]
-	__shared__ uint32_t s_hid[S_WBATCH];   // Gaussian id of compacted hit k
-	__shared__ uint32_t s_hc[S_WBATCH];    // its contributor number (0-based position in the tile's list)
-
-	SurfelBwdPix st;
-	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
-	st.pixs = mk2(-pixv.y, pixv.x);
-	// entries at or beyond the furthest last-contributor of the 64 pixels can be dropped for the whole wave
-	int wave_last = st.last_contributor;
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off));
-	wave_last = __builtin_amdgcn_readfirstlane(wave_last);   // (uniform after the butterfly; tells the compiler so)
-	if (wave_last == 0) return;
-	// where this lane parks its row totals: quad q of a row holds value slot(q) of every reduced register (row_reduce_slot)
-	const uint32_t slab_lane = (uint32_t)(lane >> 4) * S_ACC_F + (uint32_t)row_reduce_slot(lane);
-
-	// The tile's list is walked back to front in the forward's batches of 64 entries; the forward left, per batch, the mask of
-	// the entries that blended into this block (plus the rare grazing pairs): only those are differentiated.  No footprint
-	// vote and no cull-record traffic here, and no pair that cannot contribute.
-	const size_t batch0 = (size_t)(range.x / S_WBATCH) + tile;
-	for (int b = (min(wave_last, count) - 1) / S_WBATCH; b >= 0; b--) {
-		const unsigned long long* mp = blend_mask + ((batch0 + (size_t)b) * 16u + quad * 4u);
-		const unsigned long long bits = (mp[0] | mp[1]) | (mp[2] | mp[3]);
-		if (bits == 0ull) continue;
-		// ---- 1. lane l looks at batch slot 63 - l, so that ascending lanes are descending list positions
-		const int pos = b * S_WBATCH + (S_WBATCH - 1 - lane);
-		const bool hit = ((bits >> (S_WBATCH - 1 - lane)) & 1ull) != 0ull && pos < wave_last;
-		const unsigned long long mm = __ballot(hit);
-		const int nh = __popcll(mm);
-		if (nh == 0) continue;
-		// ---- 2. compact: lane k ends up holding the id / contributor number of the k-th surviving entry
-		if (hit) {
-			const int k = __popcll(mm & ((1ull << lane) - 1ull));
-			s_hid[k] = point_list[range.x + (uint32_t)pos];
-			s_hc[k] = (uint32_t)pos;
-		}
-		__syncthreads();
-		const uint32_t hid = lane < nh ? s_hid[lane] : 0u;
-		const uint32_t hc = lane < nh ? s_hc[lane] : 0u;
-		// ---- 3. differentiate the survivors.  The record of hit k is wave-uniform: its id is read into an SGPR
-		// (v_readlane) and the 80-byte record comes in through the SCALAR memory path (s_load_dwordx4) into SGPRs:
-		// no LDS staging, no vector registers for per-Gaussian data, and the next record is requested while the
-		// current one is being differentiated (two SGPR buffers ping-pong; with a single rotating buffer the compiler
-		// copies the loaded SGPRs and waits for the load immediately).
-		unsigned long long touched = 0ull;
-		using Rec = SurfelRec;
-		auto fetch = [&](int k) -> Rec {
-			const float4* q = rec + (size_t)__builtin_amdgcn_readlane(hid, k) * S_REC_F4;
-			return Rec{q[0], q[1], q[2], q[3], q[4]};
-		};
-		auto differentiate = [&](int k, const Rec& R) {
-			const int contributor = (int)__builtin_amdgcn_readlane(hc, k);
-			float v[S_ACC_F];
-			v[S_ACC_F - 1] = 0.f;
-			if (surfel_bwd_pair(st, R, pixv, contributor, inside_m, v) == 0ull) return;
-			// 20 values -> 5 registers of row totals (exchange-type DPP only); every lane of quad q of row r holds value slot(q)
-			// of each register and parks it in the slab row of (hit, r) — the four lanes of a quad store the same value to the
-			// same address, which is cheaper than masking three of them off.  The four rows are added up by the flush.
-			float z[5];
-			row_reduce20(v, z);
-			float* slab = reinterpret_cast<float*>(s_slab) + (k & (S_SUB - 1)) * 4 * S_ACC_F + slab_lane;
-#pragma unroll
-			for (int g = 0; g < 5; g++) slab[4 * g] = z[g];
-			touched |= 1ull << k;
-		};
-		// ---- 4. flush, every S_SUB hits: lane -> (hit, float d); the four row totals are added here and leave as 80
-		// contiguous bytes of float atomics per surfel
-		auto flush = [&](int k_last) {
-			const int k0 = k_last & ~(S_SUB - 1);
-			__syncthreads();
-			if (touched != 0ull && !(dev_flags & 1)) {
-				const float* slab = reinterpret_cast<const float*>(s_slab);
-				const int n = (k_last - k0 + 1) * S_ACC_F;
-				for (int item = lane; item < n; item += 64) {
-					const int kk = item / S_ACC_F, dd = item - kk * S_ACC_F;
-					if (dd < S_ACC_F - 1 && ((touched >> (k0 + kk)) & 1ull)) {
-						const float* row = slab + kk * 4 * S_ACC_F + dd;
-						atomicAdd(acc + (size_t)s_hid[k0 + kk] * S_ACC_F + dd, (row[0] + row[S_ACC_F]) + (row[2 * S_ACC_F] + row[3 * S_ACC_F]));
-					}
-				}
-			}
-			__syncthreads();
-		};
-		Rec A = fetch(0), B = A;
-		for (int k = 0; k < nh; k += 2) {
-			if (k + 1 < nh) B = fetch(k + 1);
-			differentiate(k, A);
-			if (k + 1 >= nh) { flush(k); break; }
-			if (k + 2 < nh) A = fetch(k + 2);
-			differentiate(k + 1, B);
-			if (((k + 1) & (S_SUB - 1)) == S_SUB - 1 || k + 2 >= nh) flush(k + 1);
-		}
-	}
 }
 
 // Sub-block form of the backward: the wave still owns an 8x8 pixel block, but each of its four 16-lane rows is a 4x4 pixel
@@ -978,7 +841,7 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 				float v[S_ACC_F];
 				v[S_ACC_F - 1] = 0.f;
 				// (no early exit: the masks are exact, an entry without a blending lane is a rare forced one, and then v is all zeros)
-				surfel_bwd_pair<false>(st, R, pixv, b * S_WBATCH + (int)j, inside_m & valid, v);
+				surfel_bwd_pair(st, R, pixv, b * S_WBATCH + (int)j, inside_m & valid, v);
 				// 20 values -> 5 registers of per-row totals; every lane of quad q of row r parks value slot(q) of each register
 				float z[5];
 				row_reduce20(v, z);
@@ -1008,16 +871,8 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 	}
 }
 
-// 75 VGPRs.  Measured at C3 (balanced XCD mapping) with amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE, GSR_BWD_WPE)))
-surfel_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-                              const float* __restrict__ bg, const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, int dev_flags,
-                              const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                              const float* __restrict__ dL_depths, const float* __restrict__ dL_drefl_map, float* __restrict__ acc,
-                              const unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
-	surfel_render_bwd_wave_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, bbox, cull, dev_flags, final_Ts, n_contrib, dL_dpixels,
-	                            dL_depths, dL_drefl_map, acc, blend_mask, mask_stride);
-}
+// 97 VGPRs, 9.6 KB of LDS per wave: 4 waves per SIMD.  (The shared-list form this kernel replaced, measured at C3 with
+// amdgpu_waves_per_eu = 3 / 4 / 5 / 6 / 8: 1.29 / 1.24 / 1.25 / 1.29 / 1.46 ms — occupancy beyond 4 buys nothing for a VALU-issue-bound kernel.)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WPE, GSR_BWD_WPE)))
 surfel_render_bwd_rows_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,
@@ -1285,14 +1140,9 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 	if (R > 0) {
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
-		if (option_dev() & 4)   // dev A/B: the shared-list form
-			surfel_render_bwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-			                                                         geom.bbox, option_cull(), option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers,
-			                                                         dL_drefl_strength_map, geom.acc, bin.blend_mask, bin.mask_stride);
-		else
-			surfel_render_bwd_rows_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-			                                                         option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc,
-			                                                         bin.blend_mask); }
+		surfel_render_bwd_rows_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
+		                                                         option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc,
+		                                                         bin.blend_mask); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);

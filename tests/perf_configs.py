@@ -34,6 +34,9 @@ def run(variant, P, W, H, mu, sh_degree, aa=False, iters=5, seed=1002):
 
 
 if __name__ == "__main__":
+    import os
+    if os.environ.get("GSR_DEV"):
+        _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))     # development A/B switches
     run("G", 100_000, 800, 800, -3.6, 3, aa=True)
     run("S", 100_000, 800, 800, -3.6, 3)
     run("G", 1_000_000, 1920, 1080, -4.75, 3, aa=True, seed=1003)
