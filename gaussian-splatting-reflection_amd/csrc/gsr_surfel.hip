@@ -141,17 +141,15 @@ __device__ __forceinline__ void surfel_cull_record(const M3& T, float cx, float 
 // preprocessCUDA forward (DSR forward.cu:149-253); FMA contraction off (integer outputs bit-exact vs oracle).
 // (Occupancy: 88 VGPRs = 5 waves per SIMD.  Forcing 6 / 8 with amdgpu_waves_per_eu was measured on the backward twin of this
 // kernel: 0.175 -> 0.249 / 0.321 ms at C3, the registers it gives up cost more than the waves it gains.)
-__global__ void __launch_bounds__(256)
-surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
-                         const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
-                         const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
-                         const float* __restrict__ refl, const uint8_t* __restrict__ env_scope_mask, SurfelCam cam, int* __restrict__ radii,
-                         GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights) {
+// One Gaussian of the pass; returns false where the reference's kernel returns early.  The render record (5 float4) and the
+// cull record (2 float4) are handed back in `o` instead of being stored: the wave stores them together (see the kernel).
+__device__ __forceinline__ bool
+surfel_preprocess_one(int idx, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                      const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp, const float* __restrict__ refl,
+                      const uint8_t* __restrict__ env_scope_mask, const SurfelCam& cam, int* __restrict__ radii, const GeomState& g, int gx, int gy,
+                      int prefiltered, float* __restrict__ gaussian_weights, float4* o) {
 #pragma clang fp contract(off)
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
-	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
-	if (idx >= P) return;
 	radii[idx] = 0;
 	gaussian_weights[idx] = 0.f;   // the tile kernel merges per-wave maxima into it with atomicMax
 	g.tiles_touched[idx] = 0;
@@ -163,7 +161,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
 	if (pvz <= 0.2f) {
 		if (prefiltered) g.flags[0] = 1;
-		return;
+		return false;
 	}
 	M3 T;
 	F3 normal;
@@ -178,14 +176,14 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	}
 	// DUAL_VISIABLE (forward.cu:211-216)
 	const float cosv = -((pvx * normal.x) + (pvy * normal.y) + (pvz * normal.z));
-	if (cosv == 0) return;
+	if (cosv == 0) return false;
 	const float multiplier = cosv > 0 ? 1.f : -1.f;
 	normal = f3(multiplier * normal.x, multiplier * normal.y, multiplier * normal.z);
 	// compute_aabb (forward.cu:119-145), cutoff = 3
 	const float cutoff = 3.0f;
 	const float t0 = cutoff * cutoff, t1 = cutoff * cutoff, t2 = -1.0f;
 	const float d = t0 * (T.m[2][0] * T.m[2][0]) + t1 * (T.m[2][1] * T.m[2][1]) + t2 * (T.m[2][2] * T.m[2][2]);
-	if (d == 0.0f) return;
+	if (d == 0.0f) return false;
 	const float inv_d = 1 / d;
 	const float f0 = inv_d * t0, f1 = inv_d * t1, f2 = inv_d * t2;
 	const float pxi = f0 * (T.m[0][0] * T.m[2][0]) + f1 * (T.m[0][1] * T.m[2][1]) + f2 * (T.m[0][2] * T.m[2][2]);
@@ -196,7 +194,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	const float radius = ceilf(fmaxf(fmaxf(ex, ey), cutoff * (float)0.707106));
 	uint32_t x0, y0, x1, y1;
 	get_rect(pxi, pyi, f2i(radius), gx, gy, x0, y0, x1, y1);
-	if ((x1 - x0) * (y1 - y0) == 0) return;
+	if ((x1 - x0) * (y1 - y0) == 0) return false;
 
 	float cr, cg, cb;
 	if (colors_precomp == nullptr) {
@@ -216,13 +214,8 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
 	const float maskv = (env_scope_mask != nullptr && env_scope_mask[idx]) ? 1.0f : 0.0f;
-	{
-		float4 c0, c1;
-		surfel_cull_record(T, pxi, pyi, opacities[idx], c0, c1);
-		g.bbox[2 * idx] = c0;
-		g.bbox[2 * idx + 1] = c1;
-	}
-	float4* rec = g.rec + (size_t)idx * S_REC_F4;
+	surfel_cull_record(T, pxi, pyi, opacities[idx], o[5], o[6]);
+	float4* rec = o;
 	// Render record, laid out in even-aligned PAIRS so that the tile kernels can feed them to packed fp32 instructions
 	// (v_pk_mul/add/fma_f32 take a 64-bit aligned SGPR pair) straight from the s_load destination:
 	//   {x, y | Tu.x, Tv.x} {Tu.y, Tv.y | Tu.z, Tv.z} {Tw.x, Tw.y | Tw.z, opacity} {n.x, n.y | n.z, refl} {r, g | b, mask}
@@ -232,6 +225,54 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	rec[3] = make_float4(normal.x, normal.y, normal.z, refl[idx]);
 	rec[4] = make_float4(cr, cg, cb, maskv);
 	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
+	return true;
+}
+
+// The records are AoS (80 + 32 bytes per Gaussian) because the tile kernels fetch one Gaussian's record at a time; stored by
+// the lane that computed them they are 7 store instructions of 64 x 16 bytes at an 80- or 32-byte stride — 384 of this
+// kernel's ~420 write requests per wave (TCP_TCC_WRITE_REQ, profiles/r02_pmc_memory_side.txt), every one of them a partial
+// line.  Instead each wave transposes its 64 x 7 float4 through LDS and writes 5 + 2 KB of contiguous memory.
+#define S_OUT_F4 7
+#define S_OUT_PITCH 65   // float4 per plane: 64 + 1 of padding
+__global__ void __launch_bounds__(256)
+surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                         const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                         const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
+                         const float* __restrict__ refl, const uint8_t* __restrict__ env_scope_mask, SurfelCam cam, int* __restrict__ radii,
+                         GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
+	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	__shared__ float4 s_out[4][S_OUT_F4 * S_OUT_PITCH];
+	const int lane = threadIdx.x & 63;
+	float4* so = s_out[threadIdx.x >> 6];
+	float4 o[S_OUT_F4];
+#pragma unroll
+	for (int k = 0; k < S_OUT_F4; k++) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+	bool live = false;
+	if (idx < P)
+		live = surfel_preprocess_one(idx, D, M, means, scales, scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, refl,
+		                             env_scope_mask, cam, radii, g, gx, gy, prefiltered, gaussian_weights, o);
+	if (__ballot(live) == 0ull) return;      // (wave-uniform) nothing of this wave is ever read
+#pragma unroll
+	for (int k = 0; k < S_OUT_F4; k++) so[k * S_OUT_PITCH + lane] = o[k];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	const int g0 = idx - lane;               // first Gaussian of the wave
+	const int ng = min(64, P - g0);
+	float4* rec_out = g.rec + (size_t)g0 * S_REC_F4;
+#pragma unroll
+	for (int j = 0; j < S_REC_F4; j++) {
+		const int e = lane + 64 * j, gi = e / S_REC_F4, k = e - gi * S_REC_F4;
+		if (gi < ng) rec_out[e] = so[k * S_OUT_PITCH + gi];
+	}
+	float4* bbox_out = g.bbox + (size_t)g0 * 2;
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		const int e = lane + 64 * j, gi = e >> 1, k = e & 1;
+		if (gi < ng) bbox_out[e] = so[(S_REC_F4 + k) * S_OUT_PITCH + gi];
+	}
 }
 
 // Ray-splat intersection and falloff for one (pixel, surfel) pair, shared by the forward and backward
