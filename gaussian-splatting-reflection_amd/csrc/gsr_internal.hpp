@@ -242,6 +242,53 @@ __device__ __forceinline__ void quad_sum4(float* z) {
 // lane -> pixel inside the wave's 8x8 block: 16-lane row r is the 4x4 sub-block (r & 1, r >> 1), lanes inside it row-major
 __device__ __forceinline__ int sub_px(int lane) { return ((lane >> 4) & 1) * 4 + (lane & 3); }
 __device__ __forceinline__ int sub_py(int lane) { return (lane >> 5) * 4 + ((lane >> 2) & 3); }
+// ---- wave-cooperative stores of per-Gaussian rows.  The reference's tensors are AoS ((P,3), (P,9), (P,16,3), 80-byte records ...):
+// stored by the lane that computed them, a row of N dwords is N store instructions of 64 x 4 bytes at a stride of 4N bytes —
+// 64 partial-line write requests each.  Here the wave's 64 rows, which are contiguous in memory, go through a wave-private
+// LDS tile (N planes of 65 elements) and leave as N instructions of 64 consecutive elements.  `out` points at row 0 of the
+// wave, rows beyond `nrows` are not written; ACC adds to memory instead.  All 64 lanes must be active.
+__device__ __forceinline__ void wave_lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int N, bool ACC>
+__device__ __forceinline__ void wave_store_rows(float* lds, const float* v, float* __restrict__ out, int nrows, int lane) {
+#pragma unroll
+	for (int k = 0; k < N; k++) lds[k * 65 + lane] = v[k];
+	wave_lds_sync();
+#pragma unroll
+	for (int j = 0; j < N; j++) {
+		const int e = lane + 64 * j, r = e / N, k = e - r * N;
+		if (r < nrows) {
+			const float x = lds[k * 65 + r];
+			out[e] = ACC ? out[e] + x : x;
+		}
+	}
+	wave_lds_sync();
+}
+// float4 elements; the row is N consecutive float4 starting at float4 `col0` of a row of `pitch` float4
+template <int N, bool ACC>
+__device__ __forceinline__ void wave_store_rows4(float4* lds, const float4* v, float4* __restrict__ out, int pitch, int col0, int nrows, int lane) {
+#pragma unroll
+	for (int k = 0; k < N; k++) lds[k * 65 + lane] = v[k];
+	wave_lds_sync();
+#pragma unroll
+	for (int j = 0; j < N; j++) {
+		const int e = lane + 64 * j, r = e / N, k = e - r * N;
+		if (r < nrows) {
+			const float4 x = lds[k * 65 + r];
+			float4* o = out + (size_t)r * pitch + col0 + k;
+			if (ACC) {
+				const float4 y = *o;
+				*o = make_float4(y.x + x.x, y.y + x.y, y.z + x.z, y.w + x.w);
+			} else {
+				*o = x;
+			}
+		}
+	}
+	wave_lds_sync();
+}
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (which __builtin_ctz leaves undefined)
 __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) {
 	uint32_t r;

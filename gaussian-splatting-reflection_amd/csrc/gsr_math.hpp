@@ -140,18 +140,17 @@ __device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
 }
 
 // computeColorFromSH backward (DSR backward.cu:20-139 / DGR backward.cu:23-142).
-// Writes dL_dsh[idx, 0:M, :] completely (zeros above the active degree, which the reference gets from
-// its torch::zeros) and returns the view-direction gradient w.r.t. the mean.
-template <bool ACC = false>
-__device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& s, F3 dir_orig, uint8_t clamped_bits, F3 dL_dRGB,
-                                          float* __restrict__ dL_dshs) {
+// The dL_dsh row of a Gaussian is the outer product w (one weight per coefficient, zero above the active degree) x dL_dRGB
+// (zeroed where the forward clamped the channel): sh_backward_weights leaves both and returns the view-direction gradient
+// w.r.t. the mean; sh_backward also writes the row dL_dsh[idx, 0:M, :] completely (the reference relies on torch::zeros
+// for the part above the active degree).
+__device__ __forceinline__ F3 sh_backward_weights(int deg, const ShRow& s, F3 dir_orig, uint8_t clamped_bits, F3& dL_dRGB, float* w) {
 	const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
 	const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
 	auto sh = [&](int k) { return F3{s.v[3 * k], s.v[3 * k + 1], s.v[3 * k + 2]}; };
 	dL_dRGB.x *= (clamped_bits & 1) ? 0.f : 1.f;
 	dL_dRGB.y *= (clamped_bits & 2) ? 0.f : 1.f;
 	dL_dRGB.z *= (clamped_bits & 4) ? 0.f : 1.f;
-	float w[16];
 #pragma unroll
 	for (int k = 0; k < 16; k++) w[k] = 0.f;
 	F3 dRGBdx{0, 0, 0}, dRGBdy{0, 0, 0}, dRGBdz{0, 0, 0};
@@ -193,6 +192,27 @@ __device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& 
 			}
 		}
 	}
+	const F3 dL_ddir = f3(dRGBdx.x * dL_dRGB.x + dRGBdx.y * dL_dRGB.y + dRGBdx.z * dL_dRGB.z,
+	                      dRGBdy.x * dL_dRGB.x + dRGBdy.y * dL_dRGB.y + dRGBdy.z * dL_dRGB.z,
+	                      dRGBdz.x * dL_dRGB.x + dRGBdz.y * dL_dRGB.y + dRGBdz.z * dL_dRGB.z);
+	return dnormvdv(dir_orig, dL_ddir);
+}
+// float4 number q (floats 4q .. 4q+3) of the row w x g
+__device__ __forceinline__ float4 sh_row_f4(int q, const float* w, F3 g) {
+	float e[4];
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		const int f = 4 * q + c;  // float index -> coefficient f/3, channel f%3
+		const int k = f / 3, ch = f % 3;
+		e[c] = w[k] * (ch == 0 ? g.x : (ch == 1 ? g.y : g.z));
+	}
+	return make_float4(e[0], e[1], e[2], e[3]);
+}
+template <bool ACC = false>
+__device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& s, F3 dir_orig, uint8_t clamped_bits, F3 dL_dRGB,
+                                          float* __restrict__ dL_dshs) {
+	float w[16];
+	const F3 dmean = sh_backward_weights(deg, s, dir_orig, clamped_bits, dL_dRGB, w);
 	// dL_dsh row: M*3 floats, contiguous; written as float4 when aligned
 	float* out = dL_dshs + (size_t)idx * M * 3;
 	if (((M * 3) & 3) == 0 && M <= 16) {
@@ -201,19 +221,12 @@ __device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& 
 #pragma unroll
 		for (int q = 0; q < 12; q++) {
 			if (q < nq) {
-				float e[4];
-#pragma unroll
-				for (int c = 0; c < 4; c++) {
-					const int f = 4 * q + c;  // float index -> coefficient f/3, channel f%3
-					const int k = f / 3, ch = f % 3;
-					const float g = ch == 0 ? dL_dRGB.x : (ch == 1 ? dL_dRGB.y : dL_dRGB.z);
-					e[c] = w[k] * g;
-				}
+				const float4 e = sh_row_f4(q, w, dL_dRGB);
 				if (ACC) {
 					const float4 old = o4[q];
-					o4[q] = make_float4(old.x + e[0], old.y + e[1], old.z + e[2], old.w + e[3]);
+					o4[q] = make_float4(old.x + e.x, old.y + e.y, old.z + e.z, old.w + e.w);
 				} else {
-					o4[q] = make_float4(e[0], e[1], e[2], e[3]);
+					o4[q] = e;
 				}
 			}
 		}
@@ -232,10 +245,7 @@ __device__ __forceinline__ F3 sh_backward(int idx, int deg, int M, const ShRow& 
 			out[3 * k + 2] = 0.f;
 		}
 	}
-	const F3 dL_ddir = f3(dRGBdx.x * dL_dRGB.x + dRGBdx.y * dL_dRGB.y + dRGBdx.z * dL_dRGB.z,
-	                      dRGBdy.x * dL_dRGB.x + dRGBdy.y * dL_dRGB.y + dRGBdy.z * dL_dRGB.z,
-	                      dRGBdz.x * dL_dRGB.x + dRGBdz.y * dL_dRGB.y + dRGBdz.z * dL_dRGB.z);
-	return dnormvdv(dir_orig, dL_ddir);
+	return dmean;
 }
 
 }  // namespace gsr

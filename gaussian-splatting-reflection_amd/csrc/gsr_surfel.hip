@@ -233,7 +233,6 @@ surfel_preprocess_one(int idx, int D, int M, const float* __restrict__ means, co
 // kernel's ~420 write requests per wave (TCP_TCC_WRITE_REQ, profiles/r02_pmc_memory_side.txt), every one of them a partial
 // line.  Instead each wave transposes its 64 x 7 float4 through LDS and writes 5 + 2 KB of contiguous memory.
 #define S_OUT_F4 7
-#define S_OUT_PITCH 65   // float4 per plane: 64 + 1 of padding
 __global__ void __launch_bounds__(256)
 surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
                          const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -243,7 +242,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
-	__shared__ float4 s_out[4][S_OUT_F4 * S_OUT_PITCH];
+	__shared__ float4 s_out[4][S_REC_F4 * 65];
 	const int lane = threadIdx.x & 63;
 	float4* so = s_out[threadIdx.x >> 6];
 	float4 o[S_OUT_F4];
@@ -254,25 +253,10 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 		live = surfel_preprocess_one(idx, D, M, means, scales, scale_modifier, rotations, opacities, shs, transMat_precomp, colors_precomp, refl,
 		                             env_scope_mask, cam, radii, g, gx, gy, prefiltered, gaussian_weights, o);
 	if (__ballot(live) == 0ull) return;      // (wave-uniform) nothing of this wave is ever read
-#pragma unroll
-	for (int k = 0; k < S_OUT_F4; k++) so[k * S_OUT_PITCH + lane] = o[k];
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	const int g0 = idx - lane;               // first Gaussian of the wave
 	const int ng = min(64, P - g0);
-	float4* rec_out = g.rec + (size_t)g0 * S_REC_F4;
-#pragma unroll
-	for (int j = 0; j < S_REC_F4; j++) {
-		const int e = lane + 64 * j, gi = e / S_REC_F4, k = e - gi * S_REC_F4;
-		if (gi < ng) rec_out[e] = so[k * S_OUT_PITCH + gi];
-	}
-	float4* bbox_out = g.bbox + (size_t)g0 * 2;
-#pragma unroll
-	for (int j = 0; j < 2; j++) {
-		const int e = lane + 64 * j, gi = e >> 1, k = e & 1;
-		if (gi < ng) bbox_out[e] = so[(S_REC_F4 + k) * S_OUT_PITCH + gi];
-	}
+	wave_store_rows4<S_REC_F4, false>(so, o, g.rec + (size_t)g0 * S_REC_F4, S_REC_F4, 0, ng, lane);
+	wave_store_rows4<2, false>(so, o + S_REC_F4, g.bbox + (size_t)g0 * 2, 2, 0, ng, lane);
 }
 
 // Ray-splat intersection and falloff for one (pixel, surfel) pair, shared by the forward and backward
@@ -944,8 +928,16 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
                              float* __restrict__ dL_dnormal, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
                              float* __restrict__ dL_drefl, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dtransMat,
                              float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= P) return;
+	// Outputs are AoS rows of the reference's tensors; the wave stores them together through LDS (wave_store_rows): stored by
+	// the lane that computed them this kernel issued ~970 write requests per wave, three times what its bytes need.
+	__shared__ __attribute__((aligned(16))) float s_tile[4][1368];     // 9 planes of 65 dwords or 4 planes of 65 float4, 16-byte aligned per wave
+	const int lane = threadIdx.x & 63;
+	float* tile = s_tile[threadIdx.x >> 6];
+	const int idx_raw = blockIdx.x * 256 + threadIdx.x;
+	const int g0 = idx_raw - lane, nrows = min(64, P - g0);      // the wave's first row, its rows inside the arrays
+	if (nrows <= 0) return;                                      // (wave-uniform)
+	const bool in_range = idx_raw < P;
+	const int idx = in_range ? idx_raw : P - 1;                  // lanes past the end recompute the last row; their rows are not stored
 	const float4* a4 = reinterpret_cast<const float4*>(acc + (size_t)idx * S_ACC_F);
 	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3], a4v = a4[4];
 	const float gcol[3] = {a0.x, a0.y, a0.z};
@@ -953,10 +945,10 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 	// render-accumulated dL_dtransMat; the tile kernel accumulates the Tv row with the opposite sign (see surfel_bwd_pair)
 	float dT[9] = {a2.x, a2.y, a2.z, -a2.w, -a3.x, -a3.y, a3.z, a3.w, a4v.x};
 	const float gm2x = a4v.y, gm2y = a4v.z;
-	dL_dcolor[3 * idx] = gcol[0]; dL_dcolor[3 * idx + 1] = gcol[1]; dL_dcolor[3 * idx + 2] = gcol[2];
-	put<ACC>(dL_drefl + idx, a0.w);
-	dL_dnormal[3 * idx] = gnrm[0]; dL_dnormal[3 * idx + 1] = gnrm[1]; dL_dnormal[3 * idx + 2] = gnrm[2];
-	put<ACC>(dL_dopacity + idx, a1.w);
+	if (in_range) {
+		put<ACC>(dL_drefl + idx, a0.w);
+		put<ACC>(dL_dopacity + idx, a1.w);
+	}
 
 	float dmean[3] = {0.f, 0.f, 0.f}, dscale[2] = {0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
 	float out_m2x = gm2x, out_m2y = gm2y;
@@ -1057,28 +1049,54 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 		out_m2y = (float)((double)(dTout[5] * depth) * 0.5 * (double)float(Hb));
 	}
 	if (shs != nullptr) {
-		if (visible) {
-			ShRow s;
-			load_sh(shs, idx, M, (D + 1) * (D + 1), s);
-			const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
-			const F3 dm = sh_backward<ACC>(idx, D, M, s, dir, clamped[idx], f3(gcol[0], gcol[1], gcol[2]), dL_dsh);
-			dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
-		} else if (!ACC) {
-			float* out = dL_dsh + (size_t)idx * M * 3;
-			for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+		if (M == 16) {
+			// the row is the outer product w x dL_dRGB (gsr_math.hpp): three passes of one 64-byte sector per row
+			float w[16];
+			F3 grgb = f3(0.f, 0.f, 0.f);
+#pragma unroll
+			for (int k = 0; k < 16; k++) w[k] = 0.f;
+			if (visible) {
+				ShRow s;
+				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+				grgb = f3(gcol[0], gcol[1], gcol[2]);
+				const F3 dm = sh_backward_weights(D, s, dir, clamped[idx], grgb, w);
+				dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+			}
+			float4* sh_out = reinterpret_cast<float4*>(dL_dsh) + (size_t)g0 * 12;
+#pragma unroll
+			for (int t = 0; t < 3; t++) {
+				const float4 q4[4] = {sh_row_f4(4 * t, w, grgb), sh_row_f4(4 * t + 1, w, grgb), sh_row_f4(4 * t + 2, w, grgb), sh_row_f4(4 * t + 3, w, grgb)};
+				wave_store_rows4<4, ACC>(reinterpret_cast<float4*>(tile), q4, sh_out, 12, 4 * t, nrows, lane);
+			}
+		} else if (in_range) {
+			if (visible) {
+				ShRow s;
+				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+				const F3 dm = sh_backward<ACC>(idx, D, M, s, dir, clamped[idx], f3(gcol[0], gcol[1], gcol[2]), dL_dsh);
+				dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+			} else if (!ACC) {
+				float* out = dL_dsh + (size_t)idx * M * 3;
+				for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+			}
 		}
 	}
-	dL_dmean2D[3 * idx] = out_m2x; dL_dmean2D[3 * idx + 1] = out_m2y; dL_dmean2D[3 * idx + 2] = 0.f;
-	put<ACC>(dL_dmean3D + 3 * idx, dmean[0]); put<ACC>(dL_dmean3D + 3 * idx + 1, dmean[1]); put<ACC>(dL_dmean3D + 3 * idx + 2, dmean[2]);
-#pragma unroll
-	for (int i = 0; i < 9; i++) dL_dtransMat[9 * idx + i] = dTout[i];
-	put<ACC>(dL_dscale + 2 * idx, dscale[0]); put<ACC>(dL_dscale + 2 * idx + 1, dscale[1]);
-	float4* rq = reinterpret_cast<float4*>(dL_drot) + idx;
-	if (ACC) {
-		const float4 r0 = *rq;
-		*rq = make_float4(r0.x + drot[0], r0.y + drot[1], r0.z + drot[2], r0.w + drot[3]);
-	} else {
-		*rq = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	const float m2d[3] = {out_m2x, out_m2y, 0.f};
+	wave_store_rows<3, false>(tile, gcol, dL_dcolor + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<3, false>(tile, gnrm, dL_dnormal + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<3, false>(tile, m2d, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<3, ACC>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<9, false>(tile, dTout, dL_dtransMat + (size_t)g0 * 9, nrows, lane);
+	if (in_range) {
+		put<ACC>(dL_dscale + 2 * idx, dscale[0]); put<ACC>(dL_dscale + 2 * idx + 1, dscale[1]);
+		float4* rq = reinterpret_cast<float4*>(dL_drot) + idx;
+		if (ACC) {
+			const float4 r0 = *rq;
+			*rq = make_float4(r0.x + drot[0], r0.y + drot[1], r0.z + drot[2], r0.w + drot[3]);
+		} else {
+			*rq = make_float4(drot[0], drot[1], drot[2], drot[3]);
+		}
 	}
 }
 
