@@ -78,17 +78,16 @@ __device__ __forceinline__ Cov2DCtx cov2d_ctx(float mx, float my, float mz, cons
 
 // preprocessCUDA forward (DGR forward.cu:151-269).  FMA contraction off: radii, tile rects and sort keys
 // must match the oracle bit for bit.
-__global__ void __launch_bounds__(256)
-gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
-                        const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
-                        const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp, const float* __restrict__ normals,
-                        const float* __restrict__ refl, GaussCam cam, int* __restrict__ radii, GeomState g, int gx, int gy, int prefiltered,
-                        int antialiasing) {
+// One Gaussian of the pass; returns false where the reference's kernel returns early.  The render record (4 float4), the cull
+// record (2 float4) and the 3D covariance (6 floats) are handed back instead of being stored: the wave stores them together
+// (see surfel_preprocess_kernel).
+__device__ __forceinline__ bool
+gauss_preprocess_one(int idx, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                     const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp, const float* __restrict__ normals,
+                     const float* __restrict__ refl, const GaussCam& cam, int* __restrict__ radii, const GeomState& g, int gx, int gy, int prefiltered,
+                     int antialiasing, float4* o, float* cov3D) {
 #pragma clang fp contract(off)
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
-	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
-	if (idx >= P) return;
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
 	g.depths[idx] = __int_as_float(0x7f7fffff);   // culled: sorts behind every visible Gaussian in the depth pre-sort
@@ -98,7 +97,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
 	if (pvz <= 0.2f) {  // in_frustum (DGR auxiliary.h:151-176)
 		if (prefiltered) g.flags[0] = 1;
-		return;
+		return false;
 	}
 	const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
 	const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
@@ -106,14 +105,11 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const float p_w = 1.0f / (hw + 0.0000001f);
 	const float projx = hx * p_w, projy = hy * p_w;
 
-	float cov3D[6];
 	if (cov3D_precomp != nullptr) {
 #pragma unroll
 		for (int i = 0; i < 6; i++) cov3D[i] = cov3D_precomp[6 * idx + i];
 	} else {
 		cov3d_from_scale_rot(scales + 3 * idx, scale_modifier, rotations + 4 * idx, cov3D);
-#pragma unroll
-		for (int i = 0; i < 6; i++) g.aux[6 * idx + i] = cov3D[i];
 	}
 	const Cov2DCtx k = cov2d_ctx(mx, my, mz, cam);
 	const M3 Vrk = m3_make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
@@ -126,7 +122,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const float det = cx * cz - cy * cy;
 	float h_convolution_scaling = 1.0f;
 	if (antialiasing) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det));
-	if (det == 0.0f) return;
+	if (det == 0.0f) return false;
 	const float det_inv = 1.f / det;
 	const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
 	const float mid = 0.5f * (cx + cz);
@@ -138,7 +134,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const float pix_y = (float)((((double)projy + 1.0) * cam.H - 1.0) * 0.5);
 	uint32_t x0, y0, x1, y1;
 	get_rect(pix_x, pix_y, f2i(my_radius), gx, gy, x0, y0, x1, y1);
-	if ((x1 - x0) * (y1 - y0) == 0) return;
+	if ((x1 - x0) * (y1 - y0) == 0) return false;
 
 	float cr, cg, cb;
 	if (colors_precomp == nullptr) {
@@ -157,7 +153,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	g.means2D[idx] = make_float2(pix_x, pix_y);
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
-	float4* rec = g.rec + (size_t)idx * G_REC_F4;
+	float4* rec = o;
 	rec[0] = make_float4(pix_x, pix_y, conx, cony);
 	rec[1] = make_float4(conz, opacities[idx] * h_convolution_scaling, cr, cg);
 	rec[2] = make_float4(cb, normals[3 * idx], normals[3 * idx + 1], normals[3 * idx + 2]);
@@ -171,10 +167,39 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 			const float inv_q = 1.0f / (2.0f * logf(255.0f * opac) * 1.05f + 0.1f);
 			c0.z = conx * inv_q; c0.w = cony * inv_q; c1.x = conz * inv_q; c1.w = -1.0f;
 		}
-		g.bbox[2 * idx] = c0;
-		g.bbox[2 * idx + 1] = c1;
+		o[G_REC_F4] = c0;
+		o[G_REC_F4 + 1] = c1;
 	}
 	g.tiles_touched[idx] = (y1 - y0) * (x1 - x0);
+	return true;
+}
+
+__global__ void __launch_bounds__(256)
+gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
+                        const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+                        const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp, const float* __restrict__ normals,
+                        const float* __restrict__ refl, GaussCam cam, int* __restrict__ radii, GeomState g, int gx, int gy, int prefiltered,
+                        int antialiasing) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
+	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	__shared__ float4 s_out[4][6 * 65];     // per wave: 4 planes of 65 float4 (record), then 2 (cull record), then 6 planes of 65 dwords (cov3D)
+	const int lane = threadIdx.x & 63;
+	float4* so = s_out[threadIdx.x >> 6];
+	float4 o[G_REC_F4 + 2];
+	float cov3D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+	for (int k = 0; k < G_REC_F4 + 2; k++) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+	bool live = false;
+	if (idx < P)
+		live = gauss_preprocess_one(idx, D, M, means, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, normals, refl, cam,
+		                            radii, g, gx, gy, prefiltered, antialiasing, o, cov3D);
+	if (__ballot(live) == 0ull) return;      // (wave-uniform) nothing of this wave is ever read
+	const int g0 = idx - lane;               // first Gaussian of the wave
+	const int ng = min(64, P - g0);
+	wave_store_rows4<G_REC_F4, false>(so, o, g.rec + (size_t)g0 * G_REC_F4, G_REC_F4, 0, ng, lane);
+	wave_store_rows4<2, false>(so, o + G_REC_F4, g.bbox + (size_t)g0 * 2, 2, 0, ng, lane);
+	if (cov3D_precomp == nullptr) wave_store_rows<6, false>(reinterpret_cast<float*>(so), cov3D, g.aux + (size_t)g0 * 6, ng, lane);
 }
 
 // Per (pixel, Gaussian) falloff shared VERBATIM by the forward and backward tile kernels: the backward
@@ -503,18 +528,30 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
                             float* __restrict__ dL_dcolor, float* __restrict__ dL_dnormals, float* __restrict__ dL_drefl,
                             float* __restrict__ dL_dinvdepth, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= P) return;
+	// The (P,3) / (P,6) / (P,16,3) output rows are stored by the wave together (wave_store_rows, gsr_internal.hpp).
+	__shared__ __attribute__((aligned(16))) float s_tile[4][1048];     // per wave: 6 planes of 65 dwords or 4 planes of 65 float4
+	const int lane = threadIdx.x & 63;
+	float* tile = s_tile[threadIdx.x >> 6];
+	const int idx_raw = blockIdx.x * 256 + threadIdx.x;
+	const int g0 = idx_raw - lane, nrows = min(64, P - g0);      // the wave's first row, its rows inside the arrays
+	if (nrows <= 0) return;                                      // (wave-uniform)
+	const bool in_range = idx_raw < P;
+	const int idx = in_range ? idx_raw : P - 1;                  // lanes past the end recompute the last row; their rows are not stored
 	const float4* a4 = reinterpret_cast<const float4*>(acc + (size_t)idx * G_ACC_F);
 	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
 	// pass-through outputs of the tile kernel
-	dL_dcolor[3 * idx] = a0.x; dL_dcolor[3 * idx + 1] = a0.y; dL_dcolor[3 * idx + 2] = a0.z;
-	dL_dnormals[3 * idx] = a0.w; dL_dnormals[3 * idx + 1] = a1.x; dL_dnormals[3 * idx + 2] = a1.y;
-	dL_drefl[idx] = a1.z;
-	if (has_invdepth) dL_dinvdepth[idx] = a1.w;
-	dL_dmean2D[3 * idx] = a2.x; dL_dmean2D[3 * idx + 1] = a2.y; dL_dmean2D[3 * idx + 2] = 0.f;
-	dL_dmean2D_pixels[3 * idx] = a2.z; dL_dmean2D_pixels[3 * idx + 1] = a2.w; dL_dmean2D_pixels[3 * idx + 2] = 0.f;
-	reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
+	if (in_range) {
+		dL_drefl[idx] = a1.z;
+		if (has_invdepth) dL_dinvdepth[idx] = a1.w;
+		reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
+	}
+	{
+		const float c3[3] = {a0.x, a0.y, a0.z}, n3[3] = {a0.w, a1.x, a1.y}, m3[3] = {a2.x, a2.y, 0.f}, p3[3] = {a2.z, a2.w, 0.f};
+		wave_store_rows<3, false>(tile, c3, dL_dcolor + (size_t)g0 * 3, nrows, lane);
+		wave_store_rows<3, false>(tile, n3, dL_dnormals + (size_t)g0 * 3, nrows, lane);
+		wave_store_rows<3, false>(tile, m3, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
+		wave_store_rows<3, false>(tile, p3, dL_dmean2D_pixels + (size_t)g0 * 3, nrows, lane);
+	}
 	float dL_dopac = a3.w;
 
 	float dmean[3] = {0.f, 0.f, 0.f};
@@ -640,25 +677,46 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 			drot[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
 		}
 	}
-	dL_dopacity[idx] = dL_dopac;
+	if (in_range) dL_dopacity[idx] = dL_dopac;
 	// ---- SH backward (also writes the dL_dsh row, zeros when not visible)
 	if (shs != nullptr) {
-		if (visible) {
-			ShRow s;
-			load_sh(shs, idx, M, (D + 1) * (D + 1), s);
-			const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
-			const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(a0.x, a0.y, a0.z), dL_dsh);
-			dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
-		} else {
-			float* out = dL_dsh + (size_t)idx * M * 3;
-			for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+		if (M == 16) {
+			// the row is the outer product w x dL_dRGB (gsr_math.hpp): three passes of one 64-byte sector per row
+			float w[16];
+			F3 grgb = f3(0.f, 0.f, 0.f);
+#pragma unroll
+			for (int k = 0; k < 16; k++) w[k] = 0.f;
+			if (visible) {
+				ShRow s;
+				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+				grgb = f3(a0.x, a0.y, a0.z);
+				const F3 dm = sh_backward_weights(D, s, dir, clamped[idx], grgb, w);
+				dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+			}
+			float4* sh_out = reinterpret_cast<float4*>(dL_dsh) + (size_t)g0 * 12;
+#pragma unroll
+			for (int t = 0; t < 3; t++) {
+				const float4 q4[4] = {sh_row_f4(4 * t, w, grgb), sh_row_f4(4 * t + 1, w, grgb), sh_row_f4(4 * t + 2, w, grgb), sh_row_f4(4 * t + 3, w, grgb)};
+				wave_store_rows4<4, false>(reinterpret_cast<float4*>(tile), q4, sh_out, 12, 4 * t, nrows, lane);
+			}
+		} else if (in_range) {
+			if (visible) {
+				ShRow s;
+				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
+				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
+				const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(a0.x, a0.y, a0.z), dL_dsh);
+				dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+			} else {
+				float* out = dL_dsh + (size_t)idx * M * 3;
+				for (int q = 0; q < M * 3; q++) out[q] = 0.f;
+			}
 		}
 	}
-	dL_dmean3D[3 * idx] = dmean[0]; dL_dmean3D[3 * idx + 1] = dmean[1]; dL_dmean3D[3 * idx + 2] = dmean[2];
-#pragma unroll
-	for (int i = 0; i < 6; i++) dL_dcov3D[6 * idx + i] = dcov[i];
-	dL_dscale[3 * idx] = dscale[0]; dL_dscale[3 * idx + 1] = dscale[1]; dL_dscale[3 * idx + 2] = dscale[2];
-	reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	wave_store_rows<3, false>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<6, false>(tile, dcov, dL_dcov3D + (size_t)g0 * 6, nrows, lane);
+	wave_store_rows<3, false>(tile, dscale, dL_dscale + (size_t)g0 * 3, nrows, lane);
+	if (in_range) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
 
 }  // namespace gsr
