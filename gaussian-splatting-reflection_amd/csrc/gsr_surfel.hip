@@ -1044,7 +1044,13 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 			dmean[0] = dM[2][0]; dmean[1] = dM[2][1]; dmean[2] = dM[2][2];
 		}
 		// densification signal overwrites dL_dmean2D.xy (backward.cu:656-659); it reads dL_dtransMat as stored
-		const float depth = rc[2].z;  // transMats[idx*9+8]
+		// transMats[idx*9+8] = Tw.z of the forward.  Recomputed (same expression, same order, no contraction: the same bits) unless
+		// the transform was supplied: reading it back costs a 64-byte sector per Gaussian for 4 bytes.
+		float depth;
+		{
+#pragma clang fp contract(off)
+			depth = precomp ? rc[2].z : ((mx * cam.proj[3] + my * cam.proj[7]) + mz * cam.proj[11]) + cam.proj[15];
+		}
 		out_m2x = (float)((double)(dTout[2] * depth) * 0.5 * (double)float(Wb));
 		out_m2y = (float)((double)(dTout[5] * depth) * 0.5 * (double)float(Hb));
 	}
