@@ -34,9 +34,10 @@ def _check_binning(hip, o, exact_float_state=()):
     np.testing.assert_array_equal(hip.state("clamped")[vis], o.state("clamped")[vis])
 
 
-def _run_surfel(P, W, H, seed, mu, sh_degree, bg, mask_radius=0.0, backward=True):
+def _run_surfel(P, W, H, seed, mu, sh_degree, bg, mask_radius=0.0, backward=True, sh_rows=16):
     orc = _oracle()
     kw, cam, sc = scene_kwargs("S", P, W, H, seed, mu, sh_degree, bg, mask_radius)
+    kw["shs"] = np.ascontiguousarray(kw["shs"][:, :sh_rows])
     o = orc.SurfelOracle(np.float32)
     ref = o.forward(**kw)
     hip = HipSurfel(kw)
@@ -67,9 +68,10 @@ def _run_surfel(P, W, H, seed, mu, sh_degree, bg, mask_radius=0.0, backward=True
         assert bad <= GATE_BUDGET, (k, "elementwise gate", bad)
 
 
-def _run_gauss(P, W, H, seed, mu, sh_degree, bg, antialiasing=False, backward=True):
+def _run_gauss(P, W, H, seed, mu, sh_degree, bg, antialiasing=False, backward=True, sh_rows=16):
     orc = _oracle()
     kw, cam, sc = scene_kwargs("G", P, W, H, seed, mu, sh_degree, bg)
+    kw["shs"] = np.ascontiguousarray(kw["shs"][:, :sh_rows])
     o = orc.GaussOracle(np.float32)
     ref = o.forward(antialiasing=antialiasing, **kw)
     hip = HipGauss(kw, antialiasing=antialiasing)
@@ -125,6 +127,22 @@ def test_c2_surfel_fwd_bwd():
 
 def test_c2_gauss_fwd_bwd():
     _run_gauss(100_000, 800, 800, 1002, -3.6, 3, (0, 0, 0), antialiasing=True)
+
+
+# ---- the per-Gaussian kernels store their AoS rows wave by wave (64 rows through LDS): Gaussian counts that end inside a wave,
+# exactly at one, one past it, and SH tensors whose rows are not 16 coefficients long (the row-by-row fall-back) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 5, 64, 65, 257])
+def test_gaussian_counts_around_wave_boundaries(P):
+    _run_surfel(P, 96, 64, 20 + P, -1.6, 3, (0.2, 0.1, 0.3))
+    _run_gauss(P, 96, 64, 40 + P, -1.6, 3, (0.2, 0.1, 0.3), antialiasing=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sh_degree,sh_rows", [(1, 4), (2, 9), (0, 1)])
+def test_short_sh_rows(sh_degree, sh_rows):
+    _run_surfel(700, 96, 64, 61, -2.0, sh_degree, (0, 0, 0), sh_rows=sh_rows)
+    _run_gauss(700, 96, 64, 62, -2.0, sh_degree, (0, 0, 0), sh_rows=sh_rows)
 
 
 # ---- per-wave culling must not change a single bit of any output (it only skips pairs that cannot blend) ----
