@@ -251,11 +251,16 @@ def main():
             render(views[0], None, False)
         torch.cuda.synchronize()
         nf = max(5, args.steps)
-        t1 = time.perf_counter()
-        for i in range(nf):
-            render(views[0], None, False)
-        torch.cuda.synchronize()
-        fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+        # wall clock, in five synchronised chunks, median chunk reported: this loop has one host synchronisation per iteration
+        # (num_rendered) and nothing to hide a host hiccup behind — a single allocator / GC stall of a few ms used to move the figure by 10-20 %
+        chunk, chunks = max(1, nf // 5), []
+        for c in range(5):
+            t1 = time.perf_counter()
+            for i in range(chunk):
+                render(views[0], None, False)
+            torch.cuda.synchronize()
+            chunks.append((time.perf_counter() - t1) / chunk * 1e3)
+        fwd_ms = sorted(chunks)[2]
         fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(nf + 1)]
         for i in range(nf):
             fmarks[i].record()
