@@ -230,7 +230,7 @@ surfel_preprocess_one(int idx, int D, int M, const float* __restrict__ means, co
 
 // The records are AoS (80 + 32 bytes per Gaussian) because the tile kernels fetch one Gaussian's record at a time; stored by
 // the lane that computed them they are 7 store instructions of 64 x 16 bytes at an 80- or 32-byte stride — 384 of this
-// kernel's ~420 write requests per wave (TCP_TCC_WRITE_REQ, profiles/r02_pmc_memory_side.txt), every one of them a partial
+// kernel's ~420 write requests per wave (TCP_TCC_WRITE_REQ, profiles/r02_pmc_memory_side_before_coalesced_stores.txt), every one of them a partial
 // line.  Instead each wave transposes its 64 x 7 float4 through LDS and writes 5 + 2 KB of contiguous memory.
 #define S_OUT_F4 7
 __global__ void __launch_bounds__(256)
