@@ -326,10 +326,45 @@ __device__ __forceinline__ void refl_pixel(const float* __restrict__ cam, float 
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// The pixel kernels gather the four bilinear corners of three channels: twelve 4-byte gathers per pixel from the
+// reference's planar [6][3][L][L] layout, and the texture (1.2 MB at L = 128) does not live in a 32 KB L1 — 9 M L2 read
+// requests per launch at 1080p (TCP_TCC_READ_REQ), which is what bounds a 60 us kernel.  With a texel-interleaved copy
+// [6][L][L] of float4 (made by one 5-us kernel per forward, 1.5 MB) a corner is ONE 16-byte gather.
+__global__ void __launch_bounds__(256) cubemap_interleave_kernel(const float* __restrict__ cubemap, float4* __restrict__ rgba, int L) {
+	const size_t LL = (size_t)L * L;
+	const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= 6 * LL) return;
+	const size_t f = t / LL, r = t - f * LL;
+	rgba[t] = make_float4(cubemap[(f * 3 + 0) * LL + r], cubemap[(f * 3 + 1) * LL + r], cubemap[(f * 3 + 2) * LL + r], 0.f);
+}
+// corner k of the seamless lookup, all three channels (the fourth corner of a cube vertex is the mean of the other three)
+template <bool RGBA>
+__device__ __forceinline__ void fetch_corners(const Seamless& s, int L, const float* __restrict__ cubemap, const float4* __restrict__ rgba, float (&v)[4][3]) {
+	const int nk = s.is_vertex ? 3 : 4;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		if (k < nk) {
+			if (RGBA) {
+				const float4 t = rgba[((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]];
+				v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z;
+			} else {
+#pragma unroll
+				for (int c = 0; c < 3; c++) v[k][c] = cubemap[texel(s.f[k], c, s.y[k], s.x[k], 3, L)];
+			}
+		}
+	}
+	if (s.is_vertex) {
+#pragma unroll
+		for (int c = 0; c < 3; c++) v[3][c] = (v[0][c] + v[1][c] + v[2][c]) / 3.f;
+	}
+}
+
+template <bool RGBA>
 __global__ void __launch_bounds__(256)
 deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
-                         const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L, int W,
-                         int H, float* __restrict__ out_final, float* __restrict__ out_refl, float* __restrict__ out_nworld) {
+                         const float* __restrict__ cam, const float* __restrict__ cubemap, const float4* __restrict__ rgba,
+                         const float* __restrict__ fail_value, int L, int W, int H, float* __restrict__ out_final, float* __restrict__ out_refl,
+                         float* __restrict__ out_nworld) {
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (pix >= HW) return;
@@ -350,14 +385,11 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 		cube_uv(o.rx, o.ry, o.rz, u, v, face);
 		Seamless s;
 		seamless_index(face, L, u, v, s);
+		float cv[4][3];
+		fetch_corners<RGBA>(s, L, cubemap, rgba, cv);
 #pragma unroll
-		for (int ch = 0; ch < 3; ch++) {
-			const float v00 = cubemap[texel(s.f[0], ch, s.y[0], s.x[0], 3, L)];
-			const float v01 = cubemap[texel(s.f[1], ch, s.y[1], s.x[1], 3, L)];
-			const float v10 = cubemap[texel(s.f[2], ch, s.y[2], s.x[2], 3, L)];
-			const float v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], ch, s.y[3], s.x[3], 3, L)];
-			c[ch] = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
-		}
+		for (int ch = 0; ch < 3; ch++)
+			c[ch] = (1 - s.ky) * ((1 - s.kx) * cv[0][ch] + s.kx * cv[1][ch]) + s.ky * ((1 - s.kx) * cv[2][ch] + s.kx * cv[3][ch]);
 	}
 	const float bs[3] = {b0, b1, b2};
 #pragma unroll
@@ -508,9 +540,11 @@ struct alignas(32) ReflFootprint {
 	float g[3], kx, ky;   // 20 bytes used; padded so that a record never straddles a 32-byte sector when it is gathered
 	float pad[3];
 };
+template <bool RGBA>
 __global__ void __launch_bounds__(256)
 deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
-                                 const float* __restrict__ cam, const float* __restrict__ cubemap, const float* __restrict__ fail_value, int L,
+                                 const float* __restrict__ cam, const float* __restrict__ cubemap, const float4* __restrict__ rgba,
+                                 const float* __restrict__ fail_value, int L,
                                  int W, int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color,
                                  const float* __restrict__ g_nworld, float* __restrict__ g_normal_view, float* __restrict__ g_base,
                                  float* __restrict__ g_strength, float* __restrict__ g_fail, float* __restrict__ g_scratch,
@@ -546,17 +580,14 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 	}
 	float graw[3] = {0.f, 0.f, 0.f};
 	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
+	float cv[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+	if (!fail) fetch_corners<RGBA>(s, L, cubemap, rgba, cv);
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
-		float cval, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+		float cval;
+		const float v00 = cv[0][c], v01 = cv[1][c], v10 = cv[2][c], v11 = cv[3][c];
 		if (fail) cval = fail_value[c];
-		else {
-			v00 = cubemap[texel(s.f[0], c, s.y[0], s.x[0], 3, L)];
-			v01 = cubemap[texel(s.f[1], c, s.y[1], s.x[1], 3, L)];
-			v10 = cubemap[texel(s.f[2], c, s.y[2], s.x[2], 3, L)];
-			v11 = s.is_vertex ? (v00 + v01 + v10) / 3.f : cubemap[texel(s.f[3], c, s.y[3], s.x[3], 3, L)];
-			cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
-		}
+		else cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
 		const float rc = sigmoidf_(cval);
 		const float gf = gfin[c];
 		const float b = bas[c];
@@ -784,20 +815,36 @@ extern "C" int gsr_cubemap_backward(const float* grad_outputs, const float* inpu
 	return 0;
 }
 
-extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
-                                               const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
-                                               float* out_final, float* out_refl_color, float* out_normal_world, void* stream_) {
+extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                                  const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                                  float* out_final, float* out_refl_color, float* out_normal_world, float* cubemap_rgba,
+                                                  void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !out_final ||
-	    !out_refl_color || !out_normal_world || L == 0) {
+	    !out_refl_color || !out_normal_world || L == 0 || ((uintptr_t)cubemap_rgba & 15) != 0) {
 		set_error("gsr_deferred_reflection_forward: invalid argument");
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
-{ StageTimer st_(GSR_STAGE_REFL_FWD, stream); 	deferred_refl_fwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
-	                                                                         (int)L, width, height, out_final, out_refl_color, out_normal_world); }
+	StageTimer st_(GSR_STAGE_REFL_FWD, stream);
+	const unsigned grid = (unsigned)((HW + 255) / 256);
+	if (cubemap_rgba) {
+		float4* rgba = reinterpret_cast<float4*>(cubemap_rgba);
+		cubemap_interleave_kernel<<<(unsigned)((6 * (size_t)L * L + 255) / 256), 256, 0, stream>>>(cubemap, rgba, (int)L);
+		deferred_refl_fwd_kernel<true><<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, rgba, fail_value, (int)L, width, height,
+		                                                        out_final, out_refl_color, out_normal_world);
+	} else {
+		deferred_refl_fwd_kernel<false><<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width, height,
+		                                                         out_final, out_refl_color, out_normal_world);
+	}
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
+}
+extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                               const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                               float* out_final, float* out_refl_color, float* out_normal_world, void* stream_) {
+	return gsr_deferred_reflection_forward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, out_final, out_refl_color,
+	                                          out_normal_world, nullptr, stream_);
 }
 
 // Scratch layout of the sorted-footprint backward (floats): [texel staging ntex*4][fail-value gradient 4][pad 4][footprints 8n][keys_in n][keys_out n][pixels_out n]
@@ -899,7 +946,8 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
                                                    const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                    const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                    float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
-                                                   float* scratch, size_t scratch_floats, int accumulate, int async_tail, void* stream_) {
+                                                   float* scratch, size_t scratch_floats, int accumulate, int async_tail, const float* cubemap_rgba,
+                                                   void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
 	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
@@ -928,10 +976,17 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 		uint32_t* keys_out = keys_in + rs.n;
 		uint32_t* pix_out = keys_out + rs.n;
 		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
-		deferred_refl_bwd_entries_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value,
-		                                                                                (int)L, width, height, g_final, g_refl_color, g_normal_world,
-		                                                                                g_normal_view, g_base, g_strength, fail_acc, scratch, fp, keys_in,
-		                                                                                (uint32_t)ntex, sort_temp, refl_sort_cleared_bytes(rs.key_bits, rs.n));
+		const unsigned egrid = (unsigned)((HW + 255) / 256);
+		const size_t clr = refl_sort_cleared_bytes(rs.key_bits, rs.n);
+		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
+			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
+			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
+			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc, scratch, fp,
+			                                                                 keys_in, (uint32_t)ntex, sort_temp, clr);
+		else
+			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
+			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc,
+			                                                                  scratch, fp, keys_in, (uint32_t)ntex, sort_temp, clr);
 		// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
 		hipStream_t tail = stream;
 		SideStream* side = nullptr;
@@ -970,7 +1025,8 @@ extern "C" int gsr_deferred_reflection_backward_accum(const float* normal_view, 
                                                 float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
                                                 float* scratch, size_t scratch_floats, int accumulate, void* stream_) {
 	return gsr_deferred_reflection_backward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
-	                                           g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate, 0, stream_);
+	                                           g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate, 0, nullptr,
+	                                           stream_);
 }
 
 extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,

@@ -755,7 +755,10 @@ __device__ __forceinline__ lmask surfel_bwd_pair(SurfelBwdPix& s, const SurfelRe
 // totals of a batch are parked in a slab of (row, entry) slots — slot = (entries of the rows before) + (iteration of the
 // row), plain stores, no two writers — and when the batch is done each entry's rows are added up and leave as ONE 80-byte
 // row of float atomics, as in the shared-list form.
-#define S_CAP 48      // slab slots = (sub-block, entry) pairs differentiated between two flushes; a batch with more is cut (rare)
+#ifndef S_CAP
+#define S_CAP 48
+#endif
+// S_CAP: slab slots = (sub-block, entry) pairs differentiated between two flushes; a batch with more is cut (rare)
 __device__ __forceinline__ void
 surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                             const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,

@@ -100,18 +100,20 @@ class _DeferredReflection(torch.autograd.Function):
         final = torch.empty_like(bc)
         refl_color = torch.empty_like(bc)
         normal_world = torch.empty_like(nv)
+        # texel-interleaved copy of the cubemap for the pixel kernels (one 16-byte gather per bilinear corner); the backward reuses it
+        rgba = torch.empty(6 * cm.shape[2] * cm.shape[3] * 4, dtype=torch.float32, device=cm.device)
         with torch.cuda.device(nv.device):
-            check(lib.gsr_deferred_reflection_forward(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(final),
-                                                      ptr(refl_color), ptr(normal_world), stream_ptr(nv.device)),
+            check(lib.gsr_deferred_reflection_forward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(final),
+                                                         ptr(refl_color), ptr(normal_world), ptr(rgba), stream_ptr(nv.device)),
                   "gsr_deferred_reflection_forward")
-        ctx.save_for_backward(nv, bc, rs, cm, fv, cam)
+        ctx.save_for_backward(nv, bc, rs, cm, fv, cam, rgba)
         ctx.sink = sink
         ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None instead of zero-filled [3,H,W] tensors
         return final, refl_color, normal_world
 
     @staticmethod
     def backward(ctx, g_final, g_refl_color, g_normal_world):
-        nv, bc, rs, cm, fv, cam = ctx.saved_tensors
+        nv, bc, rs, cm, fv, cam, rgba = ctx.saved_tensors
         H, W = nv.shape[1], nv.shape[2]
         g_final = torch.zeros_like(bc) if g_final is None else g_final.float().contiguous()
         g_refl_color = None if g_refl_color is None else g_refl_color.float().contiguous()
@@ -139,7 +141,7 @@ class _DeferredReflection(torch.autograd.Function):
             check(lib.gsr_deferred_reflection_backward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
                                                           ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
                                                           ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
-                                                          int(async_tail), stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+                                                          int(async_tail), ptr(rgba), stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
         if async_tail:
             _gsr.side_hold(scratch, g_cm, g_fail)     # read / written on the side stream until side_join()
         return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None, None

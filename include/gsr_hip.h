@@ -196,8 +196,15 @@ int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* b
                                         int width, int height, const float* g_final, const float* g_refl_color,
                                         const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
                                         float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
-                                        int accumulate, int async_tail, void* stream);
+                                        int accumulate, int async_tail, const float* cubemap_rgba, void* stream);
 int gsr_side_join(void* stream);
+/* Extension: cubemap_rgba (NULL, or 6*L*L*4 floats, 16-byte aligned) receives a texel-interleaved copy [6][L][L][r,g,b,0] of
+ * the cubemap, made by the call, from which the pixel kernel gathers each bilinear corner with one 16-byte load instead of
+ * three 4-byte ones; hand the same buffer to gsr_deferred_reflection_backward_ex (cubemap_rgba) of the same cubemap, or NULL. */
+int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
+                                       const float* cam, const float* cubemap, const float* fail_value, uint32_t L, int width,
+                                       int height, float* out_final, float* out_refl_color, float* out_normal_world,
+                                       float* cubemap_rgba, void* stream);
 /* Shading normal alone: out = normalize(normal_view rotated to world space) with the reference's +1e-6
  * (gaussian_renderer/__init__.py:148,178-179), for the initial stage where render() skips the reflection chain but still
  * returns rend_normal; `cam` as above (only its first nine floats are read).  The backward writes g_normal_view fully. */
