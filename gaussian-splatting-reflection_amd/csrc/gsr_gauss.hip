@@ -352,7 +352,9 @@ gauss_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 // No workgroup barriers and no waiting for sibling quadrants (the reference synchronises the 256 threads of a tile twice
 // per batch).  Variant S moved on to one list per 4x4 sub-block (surfel_render_bwd_rows_kernel); for this variant's much
 // cheaper pair that form was measured and did not pay: the per-row blend masks cost the forward more than the shorter
-// lists gave the backward (1 M Gaussians: fwd 0.265 -> 0.311 ms, bwd 0.534 -> 0.511 ms; 5 M: 0.44 -> 0.53, 0.84 -> 0.74).
+// lists gave the backward (masks tracked with scalar instructions, 1 M Gaussians: fwd 0.265 -> 0.311 ms, bwd 0.534 -> 0.511 ms; 5 M: 0.44 ->
+// 0.53, 0.84 -> 0.74; tracked per lane with two vector instructions per pair and an OR over the rows per batch: 1 M 0.263 -> 0.279,
+// 0.529 -> 0.503; 5 M 0.45 -> 0.50, 0.84 -> 0.74; 100 k both kernels slower).
 template <bool INVDEPTH>
 __global__ void __launch_bounds__(64)
 gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
