@@ -377,8 +377,6 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 	const int count = (int)(range.y - range.x);
 	const size_t HW = (size_t)H * W;
 	const size_t pix = (size_t)W * py + px;
-	const float qx0 = (float)bx0, qy0 = (float)by0, qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
-
 	__shared__ float s_slab[G_SUB * 4 * G_ACC_F];   // [hit in sub-batch][16-lane row][16 floats]
 	__shared__ uint32_t s_hid[G_WBATCH];
 	__shared__ uint32_t s_hj[G_WBATCH];
@@ -483,7 +481,7 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 			v[GA_CONIC + 1] = hg * gdx * dy;
 			v[GA_CONIC + 2] = hg * gdy * dy;
 			v[GA_OPAC] = G * dL_dalpha;
-			// 16 values -> 4 registers of row totals (exchange-type DPP, see row_reduce_groups); the four 16-lane rows park
+			// 16 values -> 4 registers of row totals (exchange-type DPP, row_reduce16); the four 16-lane rows park
 			// theirs in separate slab rows and the flush adds them
 			// (the four lanes of a quad hold the same totals and store them to the same address: cheaper than masking three off)
 			float z[4];

@@ -144,7 +144,6 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 // always >= 3 instructions after its last write (gfx9 VALU-write -> DPP-read hazard: 2 wait states; the
 // compiler's hazard recogniser does not look inside asm, hence the leading s_nop).
 #define GSR_DPP1(CTRL, i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL "\n\t"
-#define GSR_DPP8(CTRL) GSR_DPP1(CTRL, 0) GSR_DPP1(CTRL, 1) GSR_DPP1(CTRL, 2) GSR_DPP1(CTRL, 3) GSR_DPP1(CTRL, 4) GSR_DPP1(CTRL, 5) GSR_DPP1(CTRL, 6) GSR_DPP1(CTRL, 7)
 #define GSR_DPP4(CTRL) GSR_DPP1(CTRL, 0) GSR_DPP1(CTRL, 1) GSR_DPP1(CTRL, 2) GSR_DPP1(CTRL, 3)
 #define GSR_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define GSR_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0"
@@ -152,12 +151,7 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 #define GSR_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
 #define GSR_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define GSR_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
-// Sum 8 independent values across the wave; totals valid in lane 63 only.  Must be called with all 64
-// lanes active (wave-uniform control flow).
-__device__ __forceinline__ void wave_sum8(float* v) {
-	asm volatile("s_nop 1\n\t" GSR_DPP8(GSR_SHR1) GSR_DPP8(GSR_SHR2) GSR_DPP8(GSR_SHR4) GSR_DPP8(GSR_SHR8) GSR_DPP8(GSR_BC15) GSR_DPP8(GSR_BC31)
-	             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
+// Sum 4 independent values across the wave; totals valid in lane 63 only.  Must be called with all 64 lanes active.
 __device__ __forceinline__ void wave_sum4(float* v) {
 	asm volatile("s_nop 1\n\t" GSR_DPP4(GSR_SHR1) GSR_DPP4(GSR_SHR2) GSR_DPP4(GSR_SHR4) GSR_DPP4(GSR_SHR8) GSR_DPP4(GSR_BC15) GSR_DPP4(GSR_BC31)
 	             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
@@ -171,30 +165,12 @@ __device__ __forceinline__ void wave_sum4(float* v) {
 // pair's result in lanes 0-3 of each half / the second pair's in lanes 4-7; two quad_perm adds finish the row sum.
 // Result: every lane of quad q of a row holds the ROW total of value {a, c, b, d}[q]; the four row totals are combined
 // by the caller (separate LDS rows, added at the flush).
-#define GSR_DPPX(CTRL, dst, dppsrc, src) "v_add_f32_dpp %" #dst ", %" #dppsrc ", %" #src " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
 #define GSR_Q1(CTRL, i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
-// NG groups of four values v[4g..4g+3] -> z[g].  No selects: DPP's bank_mask enables the destination per bank of four
-// lanes, so level 1 is two adds into ONE register — `a + mirror(a)` written to lanes 0-7 (banks 0,1), `b + mirror(b)` to
-// lanes 8-15 (banks 2,3) — and level 2 likewise with banks {0,2} / {1,3}.  2+2 (level 1) + 2 (level 2) = 6 instructions
-// per group of four values (up8 / up4 are kept in the signature for callers; they are not needed any more).
+// No selects: DPP's bank_mask enables the destination per bank of four lanes, so level 1 is two adds into ONE register —
+// `a + mirror(a)` written to lanes 0-7 (banks 0,1), `b + mirror(b)` to lanes 8-15 (banks 2,3) — and level 2 likewise with
+// banks {0,2} / {1,3}.  2+2 (level 1) + 2 (level 2) = 6 instructions per group of four values, + 2 quad_perm adds per output.
 #define GSR_DPPB(CTRL, BANK, dst, src) "v_add_f32_dpp %" #dst ", %" #src ", %" #src " " CTRL " row_mask:0xf bank_mask:" BANK "\n\t"
-template <int NG>
-__device__ __forceinline__ void row_reduce_groups(const float* v, float* z, bool up8, bool up4) {
-	(void)up8; (void)up4;
-	float p[NG], q[NG];
-#pragma unroll
-	for (int g = 0; g < NG; g++) {
-		asm volatile("s_nop 1\n\t" GSR_DPPB("row_mirror", "0x3", 0, 2) GSR_DPPB("row_mirror", "0xc", 0, 3) GSR_DPPB("row_mirror", "0x3", 1, 4)
-		             GSR_DPPB("row_mirror", "0xc", 1, 5)
-		             : "=&v"(p[g]), "=&v"(q[g]) : "v"(v[4 * g]), "v"(v[4 * g + 1]), "v"(v[4 * g + 2]), "v"(v[4 * g + 3]));
-	}
-#pragma unroll
-	for (int g = 0; g < NG; g++) {
-		asm volatile("s_nop 1\n\t" GSR_DPPB("row_half_mirror", "0x5", 0, 1) GSR_DPPB("row_half_mirror", "0xa", 0, 2)
-		             : "=&v"(z[g]) : "v"(p[g]), "v"(q[g]));
-	}
-}
-// The same for the surfel backward's 20 values in as few issue slots as the hazards allow: the level-1 adds of all five
+// The surfel backward's 20 values in as few issue slots as the hazards allow: the level-1 adds of all five
 // groups go into two asm blocks and the level-2 + quad adds into one, ordered so that no DPP reads a register written
 // less than three instructions earlier; only the block heads need an s_nop (the compiler's hazard recogniser does not look
 // inside asm and the preceding instruction may have written an input).  40 DPP adds + 3 s_nop instead of 40 + 11.
@@ -228,16 +204,6 @@ __device__ __forceinline__ void row_reduce16(const float* v, float* z) {
 	             GSR_QB("quad_perm:[2,3,0,1]") GSR_QB("quad_perm:[1,0,3,2]")
 	             : "=&v"(z[0]), "=&v"(z[1]), "=&v"(z[2]), "=&v"(z[3])
 	             : "v"(p0), "v"(q0), "v"(p1), "v"(q1), "v"(p2), "v"(q2), "v"(p3), "v"(q3));
-}
-// levels 3 and 4 (interleaved so that no DPP reads a register written < 2 instructions before)
-__device__ __forceinline__ void quad_sum5(float* z) {
-#define GSR_Q5(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3) GSR_Q1(CTRL, 4)
-	asm volatile("s_nop 1\n\t" GSR_Q5("quad_perm:[2,3,0,1]") GSR_Q5("quad_perm:[1,0,3,2]")
-	             : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]));
-}
-__device__ __forceinline__ void quad_sum4(float* z) {
-#define GSR_Q4(CTRL) GSR_Q1(CTRL, 0) GSR_Q1(CTRL, 1) GSR_Q1(CTRL, 2) GSR_Q1(CTRL, 3)
-	asm volatile("s_nop 1\n\t" GSR_Q4("quad_perm:[2,3,0,1]") GSR_Q4("quad_perm:[1,0,3,2]") : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
 }
 // lane -> pixel inside the wave's 8x8 block: 16-lane row r is the 4x4 sub-block (r & 1, r >> 1), lanes inside it row-major
 __device__ __forceinline__ int sub_px(int lane) { return ((lane >> 4) & 1) * 4 + (lane & 3); }
@@ -299,30 +265,6 @@ __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) {
 __device__ __forceinline__ int row_reduce_slot(int lane) {
 	const int q = (lane >> 2) & 3;          // quads 0,1,2,3 hold a, c, b, d
 	return ((q & 1) << 1) | (q >> 1);
-}
-
-// single value (compiler-scheduled form; used off the hot path)
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
-__device__ __forceinline__ float dpp_add(float v) {
-	int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
-	return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-	v = dpp_add<0x111>(v);
-	v = dpp_add<0x112>(v);
-	v = dpp_add<0x114>(v);
-	v = dpp_add<0x118>(v);
-	v = dpp_add<0x142, 0xA>(v);
-	v = dpp_add<0x143, 0xC>(v);
-	return v;  // total in lane 63
-}
-// max over the wave of non-negative values; result in lane 63.  Fused v_max_f32_dpp steps (the compiler emits
-// v_mov_b32_dpp + two canonicalising v_max per step, 5 instructions, for the builtin form); out-of-row reads are 0
-// (bound_ctrl:0), which is the identity for non-negative inputs.  Must be called with all 64 lanes active.
-#define GSR_MAX1(CTRL) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\t"
-__device__ __forceinline__ float wave_max_pos(float v) {
-	asm volatile(GSR_MAX1(GSR_SHR1) GSR_MAX1(GSR_SHR2) GSR_MAX1(GSR_SHR4) GSR_MAX1(GSR_SHR8) GSR_MAX1(GSR_BC15) GSR_MAX1(GSR_BC31) : "+v"(v));
-	return v;
 }
 
 // ---- lane masks.  A per-lane predicate lives in an SGPR pair; the tile kernels keep their predicates as explicit 64-bit

@@ -36,10 +36,6 @@ __device__ __forceinline__ M3 m3_T(const M3& a) {
 		for (int n = 0; n < 3; n++) r.m[n][c] = a.m[c][n];
 	return r;
 }
-__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
-#pragma clang fp contract(off)
-	return ax * bx + ay * by + az * bz;
-}
 
 // SH constants (DSR auxiliary.h:47-64 / DGR auxiliary.h:21-38)
 #define GSR_SH_C0 0.28209479177387814f

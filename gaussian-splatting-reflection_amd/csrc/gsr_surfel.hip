@@ -3,9 +3,9 @@
 // submodules/diff-surfel-rasterization (DSR cuda_rasterizer/forward.cu, backward.cu, rasterizer_impl.cu),
 // the rasterizer gaussian_renderer/__init__.py:14,130 of the reference calls.  Design notes in DESIGN.md.
 //
-// Render record (80 bytes, five float4 per Gaussian, written by preprocess, gathered by the tile kernels):
-//   f4[0] = (x, y, Tu.x, Tu.y)   f4[1] = (Tu.z, Tv.x, Tv.y, Tv.z)   f4[2] = (Tw.x, Tw.y, Tw.z, n.x)
-//   f4[3] = (n.y, n.z, opacity, r)   f4[4] = (g, b, refl, mask)
+// Render record (80 bytes, five float4 per Gaussian, written by preprocess, gathered by the tile kernels), in even-aligned
+// pairs for packed fp32 math:  {x, y | Tu.x, Tv.x} {Tu.y, Tv.y | Tu.z, Tv.z} {Tw.x, Tw.y | Tw.z, opacity} {n.x, n.y | n.z, refl}
+// {r, g | b, mask}   (Tu, Tv, Tw = rows of the 3x3 homography "transMat").
 #include "gsr_internal.hpp"
 #include "gsr_sort.hpp"
 #include "gsr_math.hpp"
@@ -259,17 +259,10 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	wave_store_rows4<2, false>(so, o + S_REC_F4, g.bbox + (size_t)g0 * 2, 2, 0, ng, lane);
 }
 
-// Ray-splat intersection and falloff for one (pixel, surfel) pair, shared by the forward and backward
-// tile kernels (DSR forward.cu:362-410, backward.cu:292-336).  EPS is the `unstable` threshold: 1e-4 in
-// the forward, 1e-6 in the backward — a quirk of the reference that is reproduced on purpose.
+// Pairs of floats for packed fp32 math (v_pk_*_f32): the k- and l-side (or x- and y-side) of the reference's arithmetic in one register pair.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 
-// X, Y, Z hold the x, y, z components of the two plane vectors as pairs: X = (k.x, l.x) etc.
-struct SurfelPair {
-	v2f X, Y, Z, s, d;
-	float pz, inv_pz, rho3d, rho2d, depth, G, alpha;
-};
 // The five float4 of a render record by meaning (layout: see surfel_preprocess_kernel).
 struct SurfelRec {
 	float4 r0, r1, r2, r3, r4;
@@ -287,44 +280,6 @@ struct SurfelRec {
 	__device__ __forceinline__ float b() const { return r4.z; }
 	__device__ __forceinline__ float mask() const { return r4.w; }
 };
-template <bool FWD>
-__device__ __forceinline__ bool surfel_pair(const SurfelRec& R, float pixx, float pixy, SurfelPair& o) {
-#pragma clang fp contract(off)
-	// Plain IEEE mul/sub in the reference's textual order (contraction off): the plane/plane cross product
-	// cancels catastrophically in fp32 (|k|,|l| ~ pixel coordinate x T), so evaluation order changes s by
-	// ~1e-4 relative.  Matching the order makes the HIP path agree with the oracle to rounding of exp().
-	// Written on <2 x float>: each line is ONE packed instruction doing the k- and the l-side (or the x- and the y-side)
-	// of the reference's arithmetic with the same individually rounded operations.
-	const v2f pix = mk2(pixx, pixy);
-	const v2f Tw = R.Twxy();
-	o.X = pix * Tw.x - R.TuvX();          // k.x = pix.x*Tw.x - Tu.x | l.x = pix.y*Tw.x - Tv.x
-	o.Y = pix * Tw.y - R.TuvY();
-	o.Z = pix * R.Twz() - R.TuvZ();
-	const v2f a = o.Y * o.Z.yx;           // (k.y*l.z, l.y*k.z)
-	const v2f b = o.Z * o.X.yx;           // (k.z*l.x, l.z*k.x)
-	const v2f c = o.X * o.Y.yx;           // (k.x*l.y, l.x*k.y)
-	const v2f pp = mk2(a.x - a.y, b.x - b.y);
-	o.pz = c.x - c.y;
-	// straight-line code (selects, no early returns): fewer exec-mask branches in the hot loop.  (Evaluating two list
-	// entries per iteration so that the scheduler can interleave two of these chains was tried and measured 3 % slower.)
-	const bool unstable = fabsf(o.pz) < (FWD ? 1e-4f : 1e-6f);
-	o.inv_pz = div_nr(1.0f, unstable ? 1.0f : o.pz);  // (a bare 1-ulp v_rcp here costs 1e-4 in dL_dscale)
-	const v2f sr = pp * o.inv_pz;
-	o.s = mk2(unstable ? 0.f : sr.x, unstable ? 0.f : sr.y);
-	const v2f s2 = o.s * o.s;
-	o.rho3d = unstable ? 1e8f : (s2.x + s2.y);
-	o.d = R.xy() - pix;
-	const v2f d2 = o.d * o.d;
-	o.rho2d = S_FILTER_INV_SQ * (d2.x + d2.y);
-	const float rho = fminf(o.rho3d, o.rho2d);
-	const v2f st = o.s * Tw;
-	o.depth = (st.x + st.y) + R.Twz();
-	const float power = -0.5f * rho;
-	o.G = exp_neg(power);  // compensated exp (gsr_internal.hpp): plain exp2(x*log2e) is 3e-7 off, amplified ~200x by the backward
-	o.alpha = fminf(0.99f, R.opac() * o.G);
-	// reference order of the tests: depth < near, power > 0, alpha < 1/255 (DSR forward.cu:394-410)
-	return !(o.depth < S_NEAR) && !(power > 0.0f) && !(o.alpha < 1.0f / 255.0f);
-}
 
 // renderCUDA forward (DSR forward.cu:258-489), wave-per-quadrant form.
 // One 64-thread workgroup (= one wave) owns an 8x8 pixel block of a 16x16 tile and walks the tile's list front
@@ -368,7 +323,7 @@ __device__ __forceinline__ lmask surfel_fwd_pair(const SurfelRec& R, const v2f p
 	{
 #pragma clang fp contract(off)
 		// Plain IEEE mul/sub in the reference's textual order (contraction off): the plane/plane cross product cancels
-		// catastrophically in fp32, so the evaluation order is part of the result (see surfel_pair).
+		// catastrophically in fp32, so the evaluation order is part of the result.
 		const v2f Tw = R.Twxy();
 		const v2f X = pix * Tw.x - R.TuvX();          // k.x = pix.x*Tw.x - Tu.x | l.x = pix.y*Tw.x - Tv.x
 		const v2f Y = pix * Tw.y - R.TuvY();
