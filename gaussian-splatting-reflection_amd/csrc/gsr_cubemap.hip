@@ -701,8 +701,14 @@ __global__ void __launch_bounds__(256) unpack_cubemap_grad_kernel(const float4* 
 //   * the touched part of the window then goes to the staging buffer with contiguous atomics.
 // LDS float atomics run at ~4 clocks per lane and memory-side ones at ~30 G/s, so the counts are what matters: per pixel
 // ~12 / mean-run-length LDS adds (was 12) and per launch ~3 x distinct texels global adds (was 12 x pixels).
+// REFL_WIN: at 1080p a workgroup's 2048 sorted pairs span ~100 texels, so the window is mostly slack — and its size decides
+// whether this kernel, which runs on the side stream beside the tile backward, finds LDS on a CU that the tile backward
+// has filled to 154 of 160 KB: with 4096 texels (49 KB) it waited for the tile backward to drain and ran beside the
+// per-Gaussian backward instead (0.143 -> 0.163 ms); with 1024 (12 KB) it hides inside the tile backward (step 1.99 -> 1.97 ms).
 #define REFL_CHUNK 8
-#define REFL_WIN 4096u
+#ifndef REFL_WIN
+#define REFL_WIN 1024u
+#endif
 __global__ void __launch_bounds__(256) refl_run_combine_kernel(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ pix_sorted,
                                                                const ReflFootprint* __restrict__ footprints, size_t n, uint32_t L, uint32_t no_key,
                                                                float* __restrict__ g_scratch) {
