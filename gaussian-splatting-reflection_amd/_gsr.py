@@ -89,6 +89,12 @@ def _load():
     lib.gsr_ssim_l1_forward.argtypes = [P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, P, P, P]
     lib.gsr_ssim_l1_backward.restype = c_int
     lib.gsr_ssim_l1_backward.argtypes = [P, P, c_int, c_int, c_int, P, P, P, P, P, P]
+    lib.gsr_normal_loss_scratch_floats.restype = c_size_t
+    lib.gsr_normal_loss_scratch_floats.argtypes = []
+    lib.gsr_normal_loss_forward.restype = c_int
+    lib.gsr_normal_loss_forward.argtypes = [P, P, P, c_int, c_int, P, P, P]
+    lib.gsr_normal_loss_backward.restype = c_int
+    lib.gsr_normal_loss_backward.argtypes = [P, P, P, c_int, c_int, P, P, P, P]
     lib.gsr_surface_forward.restype = c_int
     lib.gsr_surface_forward.argtypes = [P, P, c_float, c_int, c_int, P, P, P]
     lib.gsr_surface_backward.restype = c_int
@@ -144,7 +150,7 @@ PYBIND = compiled_binding()
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
             "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_deferred_reflection_forward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
+            "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_normal_loss_scratch_floats", "gsr_normal_loss_forward", "gsr_normal_loss_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",

@@ -11,6 +11,7 @@
 //     by segment table, so the 59 floats per Gaussian + cubemap update in a single launch.
 #include <cstring>
 #include "gsr_internal.hpp"
+#include <algorithm>
 
 namespace gsr {
 
@@ -279,6 +280,68 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
 }  // namespace gsr
 
 using namespace gsr;
+
+// ---- normal-consistency term of the reference's training loss (train.py:182-189):
+//   normal_error = (1 - sum_c rend_normal[c] * surf_normal[c]) [* env_scope_mask];  loss = lambda * mean(normal_error)
+// five elementwise torch kernels each way at 1080p; here one pass each way.  The forward leaves sum(normal_error) (block
+// partials added in a fixed order, in double: bitwise reproducible); the caller scales by lambda / HW.  The backward takes
+// the upstream gradient of that SUM as a one-float device tensor (no host synchronisation) and writes both gradients fully.
+__global__ void __launch_bounds__(256)
+normal_loss_fwd_kernel(const float* __restrict__ rend, const float* __restrict__ surf, const float* __restrict__ mask, size_t HW, float* __restrict__ partials) {
+	__shared__ float red[4];
+	float acc = 0.f;
+	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < HW; p += (size_t)gridDim.x * 256) {
+		float e = 1.0f - (rend[p] * surf[p] + rend[HW + p] * surf[HW + p] + rend[2 * HW + p] * surf[2 * HW + p]);
+		if (mask) e *= mask[p];
+		acc += e;
+	}
+	float r4[4] = {acc, 0.f, 0.f, 0.f};
+	wave_sum4(r4);
+	if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = r4[0];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		partials[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+		partials[2 * blockIdx.x + 1] = 0.f;
+	}
+}
+__global__ void __launch_bounds__(256)
+normal_loss_bwd_kernel(const float* __restrict__ rend, const float* __restrict__ surf, const float* __restrict__ mask, size_t HW,
+                       const float* __restrict__ g_sum, float* __restrict__ g_rend, float* __restrict__ g_surf) {
+	const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (p >= HW) return;
+	const float g = -g_sum[0] * (mask ? mask[p] : 1.0f);
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		const float r = rend[c * HW + p], s = surf[c * HW + p];
+		g_rend[c * HW + p] = g * s;
+		g_surf[c * HW + p] = g * r;
+	}
+}
+#define NORMAL_LOSS_BLOCKS 1024
+extern "C" size_t gsr_normal_loss_scratch_floats(void) { return 2 * NORMAL_LOSS_BLOCKS; }
+extern "C" int gsr_normal_loss_forward(const float* rend_normal, const float* surf_normal, const float* mask, int H, int W, float* sum2,
+                                       float* scratch, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (H <= 0 || W <= 0 || !rend_normal || !surf_normal || !sum2 || !scratch) { set_error("gsr_normal_loss_forward: invalid argument"); return GSR_E_INVALID; }
+	const size_t HW = (size_t)H * W;
+	const unsigned blocks = (unsigned)std::min<size_t>(NORMAL_LOSS_BLOCKS, (HW + 255) / 256);
+	normal_loss_fwd_kernel<<<blocks, 256, 0, stream>>>(rend_normal, surf_normal, mask, HW, scratch);
+	ssim_l1_reduce_kernel<<<1, 256, 0, stream>>>(scratch, (size_t)blocks, sum2);      // sum2[0] = sum(normal_error), sum2[1] = 0
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
+extern "C" int gsr_normal_loss_backward(const float* rend_normal, const float* surf_normal, const float* mask, int H, int W, const float* g_sum,
+                                        float* g_rend_normal, float* g_surf_normal, void* stream_) {
+	hipStream_t stream = (hipStream_t)stream_;
+	if (H <= 0 || W <= 0 || !rend_normal || !surf_normal || !g_sum || !g_rend_normal || !g_surf_normal) {
+		set_error("gsr_normal_loss_backward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	const size_t HW = (size_t)H * W;
+	normal_loss_bwd_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(rend_normal, surf_normal, mask, HW, g_sum, g_rend_normal, g_surf_normal);
+	GSR_LAUNCH_CHECK(0, stream);
+	return 0;
+}
 
 extern "C" size_t gsr_ssim_l1_scratch_floats(int C, int H, int W) {
 	if (C <= 0 || H <= 0 || W <= 0) return 0;

@@ -112,3 +112,44 @@ def photometric_loss(image, gt_image, lambda_dssim=0.2):
     s = _sums(image, gt_image)
     n = image.numel()
     return (1.0 - lambda_dssim) * (s[0] / n) + lambda_dssim * (1.0 - s[1] / n)
+
+
+class _NormalErrorSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rend_normal, surf_normal, mask):
+        rn, sn = rend_normal.float().contiguous(), surf_normal.float().contiguous()
+        if rn.dim() != 3 or rn.shape[0] != 3 or rn.shape != sn.shape:
+            raise ValueError("normal_consistency_loss: expected two [3,H,W] tensors")
+        H, W = rn.shape[1], rn.shape[2]
+        mk = None
+        if mask is not None:
+            mk = mask.float().contiguous()
+            if mk.numel() != H * W:
+                raise ValueError("normal_consistency_loss: mask must have H*W elements")
+        sums = torch.empty(2, dtype=torch.float32, device=rn.device)
+        scratch = torch.empty(int(lib.gsr_normal_loss_scratch_floats()), dtype=torch.float32, device=rn.device)
+        with torch.cuda.device(rn.device):
+            check(lib.gsr_normal_loss_forward(ptr(rn), ptr(sn), ptr(mk), H, W, ptr(sums), ptr(scratch), stream_ptr(rn.device)), "gsr_normal_loss_forward")
+        ctx.save_for_backward(rn, sn, mk) if mk is not None else ctx.save_for_backward(rn, sn)
+        ctx.has_mask = mk is not None
+        return sums[0]
+
+    @staticmethod
+    def backward(ctx, g_sum):
+        saved = ctx.saved_tensors
+        rn, sn = saved[0], saved[1]
+        mk = saved[2] if ctx.has_mask else None
+        g = g_sum.float().reshape(1).contiguous()
+        g_rn, g_sn = torch.empty_like(rn), torch.empty_like(sn)
+        with torch.cuda.device(rn.device):
+            check(lib.gsr_normal_loss_backward(ptr(rn), ptr(sn), ptr(mk), rn.shape[1], rn.shape[2], ptr(g), ptr(g_rn), ptr(g_sn), stream_ptr(rn.device)),
+                  "gsr_normal_loss_backward")
+        return g_rn, g_sn, None
+
+
+def normal_consistency_loss(rend_normal, surf_normal, lambda_normal=1.0, env_scope_mask=None):
+    """train.py:182-189: lambda_normal * mean((1 - (rend_normal * surf_normal).sum(dim=0))[None] [* env_scope_mask]) as one fused
+    kernel each way (extension; the reference spells it with five torch ops).  The mask receives no gradient (it is the
+    rasterizer's binary env-scope plane, which has none in the reference's backward either)."""
+    n = rend_normal.shape[1] * rend_normal.shape[2]
+    return lambda_normal * (_NormalErrorSum.apply(rend_normal, surf_normal, env_scope_mask) / n)

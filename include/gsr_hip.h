@@ -275,6 +275,16 @@ int gsr_gather_rows(const float* src, float* dst, const int* row_map, uint64_t n
 int gsr_split_children(int n_children, int scale_dims, int N, const int* parent, const float* xyz, const float* scaling,
                        const float* rotation, const float* noise, float* child_xyz, float* child_scaling, void* stream);
 
+/* Normal-consistency term of the training loss (reference train.py:182-189): normal_error = (1 - sum_c rend_normal[c] *
+ * surf_normal[c]) [* mask], loss = lambda * mean(normal_error).  rend_normal, surf_normal: [3,H,W]; mask: [H,W] (1,H,W) or NULL.
+ * Forward: sum2[0] = sum over pixels of normal_error (sum2[1] = 0), scratch = gsr_normal_loss_scratch_floats() floats.
+ * Backward: g_sum = d loss / d sum2[0], ONE float in device memory (so that lambda / (H*W) and the upstream gradient need no
+ * host synchronisation); writes g_rend_normal and g_surf_normal ([3,H,W]) fully; the mask gets no gradient. */
+size_t gsr_normal_loss_scratch_floats(void);
+int gsr_normal_loss_forward(const float* rend_normal, const float* surf_normal, const float* mask, int H, int W, float* sum2,
+                            float* scratch, void* stream);
+int gsr_normal_loss_backward(const float* rend_normal, const float* surf_normal, const float* mask, int H, int W,
+                             const float* g_sum, float* g_rend_normal, float* g_surf_normal, void* stream);
 /* gsr_adam_step: torch.optim.Adam(lr per group, betas, eps, amsgrad=False, weight_decay=0) as the reference sets it up
  * (scene/gaussian_model.py:196-209: eight groups, eps = 1e-15), fused over ONE flat buffer: param, grad, exp_avg and
  * exp_avg_sq are float[n], 16-byte aligned, laid out identically.  `segments` (host array, at most 16, tiling [0, n) in

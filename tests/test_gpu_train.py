@@ -324,3 +324,28 @@ def test_world_size_one_rccl_step_backward_sink_allreduce_adam():
     assert (g_sunk - g_plain).abs().max().item() <= 5e-5 * den
     # identical gradients up to atomics order -> the Adam step (sign-like at step 1) lands within the learning rate
     assert (p_sunk - p_plain).abs().max().item() <= 2.1 * 0.0025 + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,use_mask", [(1080, 1920, True), (67, 131, False), (1, 1, True)])
+def test_normal_consistency_loss_matches_the_torch_expression(H, W, use_mask):
+    """utils.loss_utils.normal_consistency_loss against the reference's five torch ops (train.py:182-189) evaluated in float64:
+    value to 1e-6 relative, both gradients to 1e-6 of their maximum; twice the same value bit for bit (fixed-order reduction)."""
+    from utils.loss_utils import normal_consistency_loss
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    rn = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0).cuda().requires_grad_(True)
+    sn = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0).cuda().requires_grad_(True)
+    mask = (torch.rand(1, H, W, generator=g) < 0.7).float().cuda() if use_mask else None
+    lam = 0.05
+    loss = normal_consistency_loss(rn, sn, lam, mask)
+    (loss * 3.0).backward()
+    rd, sd = rn.detach().double().requires_grad_(True), sn.detach().double().requires_grad_(True)
+    err = (1 - (rd * sd).sum(dim=0))[None]
+    if use_mask:
+        err = err * mask.double()
+    ref = lam * err.mean()
+    (ref * 3.0).backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * max(1e-6, abs(float(ref.detach())))
+    for a, b in ((rn.grad, rd.grad), (sn.grad, sd.grad)):
+        assert (a.double() - b).abs().max() <= 1e-6 * max(float(b.abs().max()), 1e-30)
+    assert float(normal_consistency_loss(rn.detach(), sn.detach(), lam, mask)) == float(loss.detach())
