@@ -90,6 +90,9 @@ class View:
                                                  projmatrix=self.ct["projmatrix"], sh_degree=3, campos=self.ct["campos"], prefiltered=False,
                                                  debug=False)
         self.rasterizer = GaussianRasterizer(settings)
+        # what gaussian_renderer.surface_pass reads from a camera
+        self.world_view_transform, self.full_proj_transform = self.ct["viewmatrix"], self.ct["projmatrix"]
+        self.image_width, self.image_height = W, H
 
 
 def percentiles(ms):
@@ -356,9 +359,9 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
     rank's views: render -> (1 - lambda) L1 + lambda (1 - SSIM) against a synthetic ground-truth image -> backward (gradients
     accumulated on the device) -> gradient all-reduce -> Adam over all eight parameter groups.  Never `value`."""
     import _gsr
-    from gaussian_renderer import deferred_reflection
+    from gaussian_renderer import deferred_reflection, surface_pass
     from gsr_train import DEFAULT_LRS, GaussianTrainState
-    from utils.loss_utils import photometric_loss
+    from utils.loss_utils import normal_consistency_loss, photometric_loss
     H, W = args.height, args.width
     tensors = {k: v.detach().clone() for k, v in scene.p.items()}
     mask = scene.mask
@@ -380,9 +383,11 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
             base, radii, allmap, refl_map, gw = view.rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
                                                                 shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
                                                                 rotations=st.p["rotations"], env_scope_mask=mask)
-            final, _, _ = deferred_reflection(allmap[2:5], base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
+            final, _, rend_normal = deferred_reflection(allmap[2:5], base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
                                               grad_sink=frsink, accumulate=i > 0, async_tail=not args.sync_reflection_tail)
-            loss = photometric_loss(final, gt_image, 0.2)
+            # the reference's iteration (train.py:144-196): surface pass of render(), photometric + normal-consistency loss
+            surf_depth, surf_normal = surface_pass(allmap, view, 0.0)
+            loss = photometric_loss(final, gt_image, 0.2) + normal_consistency_loss(rend_normal, surf_normal, 0.05)
             loss.backward()
         st.grads.all_reduce()
         st.optimizer.step()
@@ -415,7 +420,7 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
     nv = len(views)
     return {"ms_per_step": round(fdt / args.steps * 1e3, 4), "views_per_s": round(views_total * args.steps / fdt, 3),
             "step_ms": percentiles([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]),
-            "what": "render + L1/SSIM loss + backward + grad all-reduce + fused Adam (59 floats/Gaussian + cubemap), learning rates 0 so the workload stays C3",
+            "what": "the reference's training iteration: render (rasterizer + surface pass + reflection chain) + L1/SSIM and normal-consistency losses + backward + grad all-reduce + fused Adam (59 floats/Gaussian + cubemap), learning rates 0 so the workload stays C3",
             "final_loss": round(float(loss.item()), 6),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * (1 if k == "adam" else nv)), 4) for k, v in fstages.items() if v[1] > 0}}
 
