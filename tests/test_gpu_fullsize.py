@@ -163,3 +163,30 @@ def test_c5_gauss_5m_antialiasing_inverse_depth_against_oracle():
         assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
         bad = grad_gate(gh[k], gr[k])
         assert bad <= GATE_BUDGET, (k, "elementwise gate", bad)
+
+
+def test_c3_rotated_view_and_coloured_background_against_oracle():
+    """A second full-size comparison with other list statistics: the C4 batch's last view (camera turned 21 degrees about the y
+    axis, so that part of the scene leaves the frustum and the tile lists are lopsided), a non-black background, other seeds."""
+    import math
+    from oracle import oracle as orc
+    a = math.radians(21.0)
+    c2w = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=np.float64)
+    cam = S.make_camera(W, H, R=c2w, T=np.zeros(3))
+    kw, _, _ = scene_kwargs("S", P, W, H, 2024, -4.75, 3, (0.3, 0.1, 0.6), cam=cam)
+    o = orc.SurfelOracle(np.float32)
+    ref = o.forward(**kw)
+    hip = HipSurfel(kw)
+    out = hip.out()
+    assert out["num_rendered"] == ref["num_rendered"] and (ref["radii"] == 0).mean() > 0.02      # some of the scene is culled
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
+    assert (hip.state("n_contrib") != o.state("n_contrib")).mean() <= 1e-4
+    assert psnr(out["color"], ref["color"]) >= 50
+    assert_planes_psnr(out["allmap"], ref["allmap"])
+    g = S.make_upstream_grads(H, W, 2024)
+    gr = o.backward(dL_dcolor=g["dL_dcolor"], dL_dallmap=g["dL_dplanes"], dL_drefl_strength_map=g["dL_drefl"])
+    gh = hip.backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_drefl_strengths"):
+        assert rel_maxnorm(gh[k].reshape(gr[k].shape), gr[k]) <= 1e-4, k
+        assert grad_gate(gh[k], gr[k]) <= GATE_BUDGET, (k, "elementwise gate")
