@@ -41,13 +41,6 @@ VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VA
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
-def yaw_camera(S, W, H, deg):
-    """Base C3 camera (R = I, T = 0) rotated about the y axis by `deg` degrees: view v looks 3 v degrees to the side."""
-    a = math.radians(deg)
-    c2w = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=np.float64)
-    return S.make_camera(W, H, R=c2w, T=np.zeros(3))
-
-
 class Scene:
     """Parameters of the synthetic scene as leaf tensors whose .grad are views into ONE flat buffer
     (gsr_dist.FlatGrads: the all-reduce payload, 59 floats per Gaussian + cubemap texels + fail value)."""
@@ -82,7 +75,7 @@ class View:
 
     def __init__(self, S, index, W, H, dev):
         from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-        cam = yaw_camera(S, W, H, 3.0 * index)
+        cam = S.yaw_camera(W, H, 3.0 * index)     # view v of the batch looks 3 v degrees to the side
         self.ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
         self.HWK = (H, W, cam["K"])
         settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],

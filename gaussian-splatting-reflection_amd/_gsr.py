@@ -154,32 +154,36 @@ EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_b
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",
-          "refl_bwd", "cubemap_fwd", "cubemap_bwd", "loss_fwd", "loss_bwd", "adam", "surface_fwd", "surface_bwd"]
+          "refl_bwd", "cubemap_fwd", "cubemap_bwd", "loss_fwd", "loss_bwd", "adam", "surface_fwd", "surface_bwd", "refl_bwd_tail"]
 
 
 def set_option(name, value):
     check(lib.gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")
 
 
-_side_held = []
+_side_held = {}          # device index -> tensors the side stream of THAT device still reads or writes
 
 
 def side_hold(*tensors):
     """Keeps device tensors alive that work on the library's side stream still reads (see side_join)."""
-    _side_held.extend(tensors)
+    for t in tensors:
+        _side_held.setdefault(t.device.index if t.device.index is not None else torch.cuda.current_device(), []).append(t)
 
 
 def side_join(device=None):
     """Makes the current stream of `device` wait for everything the library has put on its side stream (the texel-gradient tail
     of deferred_reflection(..., async_tail=True)), then lets go of the scratch tensors held for it.  No host synchronisation.
     Call before anything reads the cubemap / fail-value gradient sink: gsr_dist.FlatGrads and gsr_train.FlatAdam do."""
-    import torch
-    if not _side_held:
-        return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    # always ask the library (a stream-wait on an event that has completed, or was never recorded, costs nothing): a second
+    # consumer stream must be ordered behind the tail too, and another device's held tensors are none of this call's business
     with torch.cuda.device(dev):
         check(lib.gsr_side_join(torch.cuda.current_stream(dev).cuda_stream), "gsr_side_join")
-    _side_held.clear()
+    # the tensors go back to the caching allocator, which hands them out again to work on the CURRENT stream: that work is
+    # ordered behind the join just made, so the tail can no longer be reading them
+    _side_held.pop(dev.index, None)
 
 
 def profile_enable(on=True):

@@ -6,6 +6,7 @@
 #include <cstring>
 #include "gsr_internal.hpp"
 #include <mutex>
+#include <memory>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "gsr_sort.hpp"
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -914,7 +915,7 @@ namespace {
 struct SideStream {
 	hipStream_t stream = nullptr;
 	hipEvent_t fork = nullptr, done = nullptr;
-	bool pending = false;
+	bool recorded = false;      // `done` has been recorded at least once (an event that was never recorded must not be waited on)
 };
 std::mutex g_side_mu;
 SideStream g_side[64];
@@ -941,10 +942,9 @@ extern "C" int gsr_side_join(void* stream_) {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
 	SideStream& s = g_side[dev];
-	if (s.stream && s.pending) {
-		GSR_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, s.done, 0));
-		s.pending = false;
-	}
+	// Every joining stream waits on the LAST recorded `done` (not cleared by the first waiter: an all-reduce stream and then an
+	// optimizer stream may both consume the sink); waiting on an event that has already completed costs nothing on the device.
+	if (s.stream && s.recorded) GSR_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_, s.done, 0));
 	return 0;
 }
 
@@ -967,7 +967,7 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 	float* fail_acc = scratch + ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
 	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 30) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
 	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, (ntex + 1) * 4 * sizeof(float), stream));
-	StageTimer st_(GSR_STAGE_REFL_BWD, stream);
+	auto st_ = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD, stream);      // the pixel kernel; the texel-gradient tail is GSR_STAGE_REFL_BWD_TAIL
 	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
 	if (!binned) {
 		// texel gradients by float atomics straight from the pixel kernel (memory-side, ~2.5 requests per pixel)
@@ -994,6 +994,7 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc,
 			                                                                  scratch, fp, keys_in, (uint32_t)ntex, sort_temp, clr);
 		// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
+		st_.reset();
 		hipStream_t tail = stream;
 		SideStream* side = nullptr;
 		std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
@@ -1007,14 +1008,18 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 			}
 		}
 		size_t sb = rs.sort_bytes;
+		{
+		// the tail has its own stage (timed on the stream it runs on): with async_tail it is NOT inside GSR_STAGE_REFL_BWD's events
+		StageTimer tail_timer(GSR_STAGE_REFL_BWD_TAIL, tail);
 		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true));
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, tail>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 		auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
 		unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, tail>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
+		}
 		if (side) {
 			GSR_HIP_CHECK(hipEventRecord(side->done, side->stream));
-			side->pending = true;
+			side->recorded = true;
 		}
 		GSR_LAUNCH_CHECK(0, stream);
 		return 0;

@@ -757,6 +757,7 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 		return GSR_E_INVALID;
 	}
 	if (D < 0 || D > 3 || (shs && (D + 1) * (D + 1) > M)) { set_error("gsr_gauss_forward: SH degree %d not supported with M=%d", D, M); return GSR_E_INVALID; }
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(shs, "shs (rows of a multiple of 16 bytes)");
 	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
 	const int ntiles = tiles_x * tiles_y;
 
@@ -816,6 +817,10 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 		set_error("gsr_gauss_backward: missing required pointer");
 		return GSR_E_INVALID;
 	}
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(shs, "shs (rows of a multiple of 16 bytes)");
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(dL_dsh, "dL_dsh");
+	GSR_REQUIRE_ALIGNED16(dL_drot, "dL_drot");
+	GSR_REQUIRE_ALIGNED16(dL_dconic, "dL_dconic");
 	const size_t HW = (size_t)width * height;
 	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
 	const int ntiles = tiles_x * tiles_y;

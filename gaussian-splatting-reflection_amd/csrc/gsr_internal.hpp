@@ -30,6 +30,18 @@ void set_error(const char* fmt, ...);
 		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));          \
 	} while (0)
 
+// 128-bit accesses: the per-Gaussian kernels read an SH row whose length is a multiple of 16 bytes as float4, and store dL_dsh rows
+// (M = 16) and dL_drot rows as float4.  torch allocations are 256-byte aligned; VIEWS into a packed buffer (gradient sinks) need not be.
+// Checked at the C ABI so that a misaligned caller gets GSR_E_INVALID instead of a faulting or sector-splitting kernel.
+static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+#define GSR_REQUIRE_ALIGNED16(ptr, what)                                                                      \
+	do {                                                                                                      \
+		if ((ptr) && gsr::misaligned16(ptr)) {                                                                \
+			gsr::set_error("%s: %s must be 16-byte aligned (float4 accesses); got %p", __func__, what, (const void*)(ptr)); \
+			return GSR_E_INVALID;                                                                             \
+		}                                                                                                     \
+	} while (0)
+
 // ------------------------------------------------------------------ per-stage timing (off by default)
 // RAII: records a start event at construction and a stop event at destruction on `stream` when profiling
 // is enabled (gsr_profile_enable); a no-op otherwise.

@@ -1101,6 +1101,7 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 		return GSR_E_INVALID;
 	}
 	if (D < 0 || D > 3 || (shs && (D + 1) * (D + 1) > M)) { set_error("gsr_surfel_forward: SH degree %d not supported with M=%d", D, M); return GSR_E_INVALID; }
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(shs, "shs (rows of a multiple of 16 bytes)");
 	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
 	const int ntiles = tiles_x * tiles_y;
 
@@ -1152,6 +1153,9 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 		set_error("gsr_surfel_backward: missing required pointer");
 		return GSR_E_INVALID;
 	}
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(shs, "shs (rows of a multiple of 16 bytes)");
+	if (shs && ((M * 3) & 3) == 0) GSR_REQUIRE_ALIGNED16(dL_dsh, "dL_dsh");
+	GSR_REQUIRE_ALIGNED16(dL_drot, "dL_drot");
 	const size_t HW = (size_t)width * height;
 	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
 	const int ntiles = tiles_x * tiles_y;

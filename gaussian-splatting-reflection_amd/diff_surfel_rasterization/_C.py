@@ -73,6 +73,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     gsr_dist.FlatGrads); the per-Gaussian backward kernel then writes — or, with accumulate=True, ADDS — those gradients
     straight into them and the corresponding entries of the return tuple are those same tensors.  The sink belongs to
     this call: there is no module-level state."""
+    M = sh.size(1) if sh.numel() != 0 else 0
+    if grad_sink:
+        unknown = set(grad_sink) - SINKABLE
+        if unknown:
+            raise ValueError(f"grad sink: unknown gradient name(s) {sorted(unknown)}; expected a subset of {sorted(SINKABLE)}")
+    if accumulate and (not grad_sink or not set(grad_sink) >= (SINKABLE - ({"shs"} if M == 0 else set()))):
+        # the kernel has ONE accumulate switch for all six parameter gradients: fresh (uninitialised) tensors cannot be added to
+        raise ValueError("accumulate=True needs a sink for every parameter gradient: " + ", ".join(sorted(SINKABLE)))
     if _gsr.PYBIND is not None and not grad_sink:
         return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
             background, means3D, radii, colors, refl_strengths, scales, rotations, float(scale_modifier), transMat_precomp, viewmatrix, projmatrix,
@@ -86,19 +94,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
         require_cuda(t, name)
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
-    M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
     o = dict(dtype=torch.float32, device=dev)
     # the library writes every element, so no zero-fill is needed (the reference uses torch::zeros)
     mk0 = torch.empty if P != 0 else torch.zeros
 
-    if grad_sink:
-        unknown = set(grad_sink) - SINKABLE
-        if unknown:
-            raise ValueError(f"grad sink: unknown gradient name(s) {sorted(unknown)}; expected a subset of {sorted(SINKABLE)}")
-    if accumulate and (not grad_sink or not set(grad_sink) >= (SINKABLE - ({"shs"} if M == 0 else set()))):
-        # the kernel has ONE accumulate switch for all six parameter gradients: fresh (uninitialised) tensors cannot be added to
-        raise ValueError("accumulate=True needs a sink for every parameter gradient: " + ", ".join(sorted(SINKABLE)))
 
     def mk(shape, sink_name=None, **kw):
         # gradient sink: the kernel writes this output straight into a caller-owned tensor
@@ -106,6 +106,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
         if t is not None:
             if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
                 raise ValueError(f"grad sink '{sink_name}': expected contiguous float32 {tuple(shape)} on {dev}, got {tuple(t.shape)} {t.dtype}")
+            if t.data_ptr() % 16:
+                # the kernel stores dL_dsh / dL_drot rows as float4 (include/gsr_hip.h, "alignment"); the C ABI refuses too
+                raise ValueError(f"grad sink '{sink_name}': storage must be 16-byte aligned (got {t.data_ptr():#x}); pad the slices of a packed buffer "
+                                 "to multiples of 4 floats as gsr_dist.FlatGrads does")
             return t
         return mk0(shape, **kw)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = mk((P, 3), "means3D", **o), mk((P, 3), **o), mk((P, NUM_CHANNELS), **o), mk((P, 3), **o)

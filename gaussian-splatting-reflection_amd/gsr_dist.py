@@ -26,9 +26,9 @@ class FlatGrads:
         """params: dict name -> leaf tensor (requires_grad).  Order of the dict = order in the buffer."""
         self.params = params
         self.names = list(params.keys())
-        total = sum(p.numel() for p in params.values())
+        # every slice starts on a 16-byte boundary (as gsr_train.FlatParams does): the per-Gaussian backward kernels store
+        # dL_dsh and dL_drot rows as float4 into these views when they are gradient sinks, whatever P is
         first = next(iter(params.values()))
-        self.flat = torch.zeros(total, dtype=torch.float32, device=first.device)
         self.slices = {}
         off = 0
         for k, p in params.items():
@@ -36,8 +36,11 @@ class FlatGrads:
                 raise TypeError(f"{k}: FlatGrads packs float32 parameters only")
             n = p.numel()
             self.slices[k] = (off, off + n)
-            p.grad = self.flat[off:off + n].view(p.shape)
-            off += n
+            off += (n + 3) // 4 * 4
+        self.flat = torch.zeros(off, dtype=torch.float32, device=first.device)
+        for k, p in params.items():
+            a, b = self.slices[k]
+            p.grad = self.flat[a:b].view(p.shape)
 
     @classmethod
     def mirroring(cls, flat_params):

@@ -71,6 +71,14 @@ def look_at_camera(W, H, eye, target=(0, 0, 0), up=(0, -1, 0), fovy_deg=50.0):
     return make_camera(W, H, fovy_deg, R=c2w, T=T)
 
 
+def yaw_camera(W, H, deg):
+    """The C3 camera (R = I, T = 0) turned about the y axis by `deg` degrees.  View v of the C4 batch of bench.py looks 3 v degrees
+    to the side (the C3 scene lives in a box in front of the C3 camera; the eight views see it with increasingly lopsided lists)."""
+    a = math.radians(deg)
+    c2w = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], dtype=np.float64)
+    return make_camera(W, H, R=c2w, T=np.zeros(3))
+
+
 def circle_cameras(W, H, n=8, radius=5.0, fovy_deg=50.0):
     """C4 views: n cameras on a circle of radius 5 in the xz-plane, height 0.5*sin(k), looking at the origin."""
     cams = []

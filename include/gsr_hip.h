@@ -19,6 +19,12 @@
  * call with the exact byte size and must return a device pointer aligned to >= 256 bytes that
  * stays valid until the matching backward call has completed.  The layout inside the buffers
  * is private to this library and differs from the reference's.
+ *
+ * Alignment: tensors that are accessed with 128-bit loads/stores must be 16-byte aligned — shs
+ * and dL_dsh when a row (3*M floats) is a multiple of 16 bytes (M = 4, 8, 12, 16), dL_drot,
+ * and variant G's dL_dconic.  Fresh torch allocations always are; VIEWS into a packed buffer
+ * (gradient sinks) are only if every slice starts at a multiple of 4 floats.  A misaligned
+ * pointer is refused with GSR_E_INVALID (no kernel is launched).
  */
 #ifndef GSR_HIP_H_
 #define GSR_HIP_H_
@@ -323,7 +329,8 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 #define GSR_STAGE_ADAM 14
 #define GSR_STAGE_SURFACE_FWD 15
 #define GSR_STAGE_SURFACE_BWD 16
-#define GSR_STAGE_COUNT 17
+#define GSR_STAGE_REFL_BWD_TAIL 17   /* texel-gradient tail of the reflection backward (sort + run combine + unpack); on the side stream with async_tail */
+#define GSR_STAGE_COUNT 18
 /* Test/diagnostic switches.  "cull" (default 1): per-wave footprint culling inside the tile kernels (each wave votes
  * which list entries can reach its 8x8 pixel block at all); outputs are bit-identical with 0 and 1, it only skips
  * (wave, Gaussian) pairs that cannot blend.  "dev" (default 0): development ablation bits, not for production. */

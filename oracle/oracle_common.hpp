@@ -345,4 +345,44 @@ template <class R> inline void to_float(const std::vector<R>& s, std::vector<flo
 	for (size_t i = 0; i < s.size(); i++) d[i] = (float)s[i];
 }
 
+// Tile-private accumulation for the render backward kernels (round 3).  The reference adds every (pixel, Gaussian) contribution to
+// global per-Gaussian arrays with atomicAdd; the oracle sums the same contributions in double.  All pixels of a tile walk ONE list,
+// so a tile sums into a private row per list entry and adds that row to the shared vectors once (`flush`): the number of atomic
+// read-modify-writes falls from (pixels x entries x values) to (entries x values) per tile and the all-core run scales, while the
+// per-pixel arithmetic — what the restatement is about — is exactly what it was.  Sums are in double in both forms, so results
+// move by ~1e-16 relative (summation order) at most.
+struct TileAccum {
+	struct Target { std::vector<double>* v; int stride; };
+	const Target* targets;
+	int ntargets, width = 0;
+	int base[16];
+	std::vector<double> rows;
+	double* row = nullptr;
+	TileAccum(const Target* t, int n, size_t entries) : targets(t), ntargets(n) {
+		for (int k = 0; k < n; k++) { base[k] = width; width += t[k].stride; }
+		rows.assign(entries * (size_t)width, 0.0);
+	}
+	void entry(size_t e) { row = rows.data() + e * (size_t)width; }            // the list entry the following add() calls belong to
+	void add(const std::vector<double>& v, size_t i, double val) {             // i = id * stride + component, as the callers index the shared vector
+		for (int k = 0; k < ntargets; k++)
+			if (targets[k].v == &v) { row[base[k] + (int)(i % (size_t)targets[k].stride)] += val; return; }
+	}
+	void flush(const uint32_t* ids) {                                          // ids[e] = Gaussian of list entry e
+		const size_t n = width ? rows.size() / (size_t)width : 0;
+		for (size_t e = 0; e < n; e++) {
+			const double* r = rows.data() + e * (size_t)width;
+			for (int k = 0; k < ntargets; k++) {
+				double* dst = targets[k].v->data() + (size_t)ids[e] * targets[k].stride;
+				for (int c = 0; c < targets[k].stride; c++) {
+					const double val = r[base[k] + c];
+					if (val != 0.0) {
+#pragma omp atomic
+						dst[c] += val;
+					}
+				}
+			}
+		}
+	}
+};
+
 }  // namespace orc

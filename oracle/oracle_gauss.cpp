@@ -205,14 +205,15 @@ static void render_bwd(const GaussIn<R>& in, const GaussState<R>& st, const R* c
                        const R* dL_drefl_map, const R* dL_invdepths, GaussGrads<R>& g) {
 	const int W = in.W, H = in.H;
 	const R ddelx_dx = R(0.5 * W), ddely_dy = R(0.5 * H);
-	auto add = [](std::vector<double>& v, size_t i, R val) {
-#pragma omp atomic
-		v[i] += (double)val;
-	};
+	// tile-private accumulation rows, flushed once per (tile, list entry): see TileAccum in oracle_common.hpp and oracle_surfel.cpp
+	const TileAccum::Target targets[] = {{&g.mean2D, 3}, {&g.mean2D_pixels, 3}, {&g.conic, 4}, {&g.opacity, 1}, {&g.colors, 3}, {&g.normals, 3},
+	                                     {&g.refl, 1}, {&g.invdepth, 1}};
 #pragma omp parallel for schedule(dynamic, 4) collapse(2)
 	for (int ty = 0; ty < st.gy; ty++)
 		for (int tx = 0; tx < st.gx; tx++) {
 			uint32_t rs = st.bin.ranges[2 * (ty * st.gx + tx)], re = st.bin.ranges[2 * (ty * st.gx + tx) + 1];
+			TileAccum acc(targets, sizeof(targets) / sizeof(targets[0]), re - rs);
+			auto add = [&acc](std::vector<double>& v, size_t i, R val) { acc.add(v, i, (double)val); };
 			for (int ly = 0; ly < BLOCK_Y; ly++)
 				for (int lx = 0; lx < BLOCK_X; lx++) {
 					int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -235,6 +236,7 @@ static void render_bwd(const GaussIn<R>& in, const GaussState<R>& st, const R* c
 						contributor--;
 						if ((int)contributor >= last_contributor) continue;
 						int id = st.bin.point_list[e];
+						acc.entry(e - rs);
 						R dx = st.means2D[2 * id] - pixf.x, dy = st.means2D[2 * id + 1] - pixf.y;
 						const R* co = &st.conic_opacity[4 * id];
 						const R power = R(-0.5f) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
@@ -295,6 +297,7 @@ static void render_bwd(const GaussIn<R>& in, const GaussState<R>& st, const R* c
 						add(g.opacity, id, G * dL_dalpha);
 					}
 				}
+			acc.flush(st.bin.point_list.data() + rs);
 		}
 }
 

@@ -184,6 +184,7 @@ static void render_fwd(const SurfelIn<R>& in, SurfelState<R>& st, const R* featu
 	for (int ty = 0; ty < st.gy; ty++)
 		for (int tx = 0; tx < st.gx; tx++) {
 			uint32_t rs = st.bin.ranges[2 * (ty * st.gx + tx)], re = st.bin.ranges[2 * (ty * st.gx + tx) + 1];
+			std::vector<double> tile_w(re - rs, 0.0);
 			for (int ly = 0; ly < BLOCK_Y; ly++)
 				for (int lx = 0; lx < BLOCK_X; lx++) {
 					int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -241,18 +242,10 @@ static void render_fwd(const SurfelIn<R>& in, SurfelState<R>& st, const R* featu
 						if (in.env_scope_mask && in.env_scope_mask[id]) mask = 1;
 						T = test_T;
 						last_contributor = contributor;
-						// forward.cu:458-459 (racy max in the reference; true max here)
-						double wd = (double)w;
-						double cur;
-#pragma omp atomic read
-						cur = gw[id];
-						while (wd > cur) {
-#pragma omp critical(gw_max)
-							{
-								if (wd > gw[id]) gw[id] = wd;
-								cur = gw[id];
-							}
-						}
+						// forward.cu:458-459 (racy max in the reference; true max here).  The maximum over the tile's pixels is taken
+						// privately per list entry and merged once per tile (a maximum does not depend on the order): one critical
+						// section per tile instead of one per blended pair
+						tile_w[e - rs] = std::max(tile_w[e - rs], (double)w);
 					}
 					st.final_T[pix_id] = T;
 					st.n_contrib[pix_id] = last_contributor;
@@ -268,6 +261,11 @@ static void render_fwd(const SurfelIn<R>& in, SurfelState<R>& st, const R* featu
 					out_others[pix_id + 6 * HW] = distortion;
 					out_others[pix_id + 7 * HW] = mask;
 				}
+#pragma omp critical(gw_max)
+			for (uint32_t e = rs; e < re; e++) {
+				const int id = st.bin.point_list[e];
+				if (tile_w[e - rs] > gw[id]) gw[id] = tile_w[e - rs];
+			}
 		}
 	for (int i = 0; i < in.P; i++) gaussian_weights[i] = (R)gw[i];
 }
@@ -308,14 +306,18 @@ static void render_bwd(const SurfelIn<R>& in, const SurfelState<R>& st, const R*
                        const R* dL_depths, const R* dL_drefl_map, SurfelGrads& g) {
 	const int W = in.W, H = in.H;
 	const size_t HW = (size_t)H * W;
-	auto add = [](std::vector<double>& v, size_t i, R val) {
-#pragma omp atomic
-		v[i] += (double)val;
-	};
+	// Accumulation (the reference's atomicAdd targets): every value a pixel contributes is summed in double.  The 256 pixels of a
+	// tile walk the same list, so a tile first sums into a PRIVATE row per list entry (TileAccum, oracle_common.hpp) and adds
+	// each row to the shared per-Gaussian vectors once, when the tile is done: R x 19 atomic adds instead of one per (pixel,
+	// Gaussian, value) — the per-pixel arithmetic below is untouched, only where its results are added changed (round 3: the
+	// all-atomic form made 256 host cores slower than one).
+	const TileAccum::Target targets[] = {{&g.transMat, 9}, {&g.mean2D, 3}, {&g.normal3D, 3}, {&g.opacity, 1}, {&g.colors, 3}, {&g.refl, 1}};
 #pragma omp parallel for schedule(dynamic, 4) collapse(2)
 	for (int ty = 0; ty < st.gy; ty++)
 		for (int tx = 0; tx < st.gx; tx++) {
 			uint32_t rs = st.bin.ranges[2 * (ty * st.gx + tx)], re = st.bin.ranges[2 * (ty * st.gx + tx) + 1];
+			TileAccum acc(targets, sizeof(targets) / sizeof(targets[0]), re - rs);
+			auto add = [&acc](std::vector<double>& v, size_t i, R val) { acc.add(v, i, (double)val); };
 			for (int ly = 0; ly < BLOCK_Y; ly++)
 				for (int lx = 0; lx < BLOCK_X; lx++) {
 					int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -346,6 +348,7 @@ static void render_bwd(const SurfelIn<R>& in, const SurfelState<R>& st, const R*
 						contributor--;
 						if ((int)contributor >= last_contributor) continue;
 						int id = st.bin.point_list[e];
+						acc.entry(e - rs);
 						V2<R> xy = {st.means2D[2 * id], st.means2D[2 * id + 1]};
 						const R* tm = transMats + 9 * id;
 						V3<R> Tu = {tm[0], tm[1], tm[2]}, Tv = {tm[3], tm[4], tm[5]}, Tw = {tm[6], tm[7], tm[8]};
@@ -441,6 +444,7 @@ static void render_bwd(const SurfelIn<R>& in, const SurfelState<R>& st, const R*
 						add(g.opacity, id, G * dL_dalpha);
 					}
 				}
+			acc.flush(st.bin.point_list.data() + rs);
 		}
 }
 

@@ -252,6 +252,48 @@ def test_grad_sink_accumulates_views_on_the_device():
         HipSurfel(kwa, make_sink=lambda h: ({"means3D": box["fg"].view("means3D")}, True)).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
 
 
+@pytest.mark.parametrize("P", [257, 1023])
+def test_grad_sink_with_odd_gaussian_count_stays_16_byte_aligned(P):
+    """P not a multiple of 4: the packed flat buffer pads every slice to 4 floats, so the float4 stores of dL_dsh / dL_drot into
+    the sink views stay aligned (overwrite, then accumulate a second backward); a deliberately misaligned sink is refused
+    loudly by the binding (ValueError) instead of reaching the kernel."""
+    from gsr_dist import FlatGrads
+    kw, _, _ = scene_kwargs("S", P, 160, 128, 79, -2.4, 3, (0, 0, 0))
+    g = S.make_upstream_grads(128, 160, 7)
+    plain = HipSurfel(kw).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    box = {}
+
+    def make_sink(acc):
+        def f(hip):
+            if "fg" not in box:
+                box["fg"] = FlatGrads(_sink_params(hip))
+                box["fg"].flat.fill_(float("nan"))
+            return box["fg"].sink(), acc
+        return f
+    HipSurfel(kw, make_sink=make_sink(False)).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    fg = box["fg"]
+    for k in _GRAD_NAMES:
+        assert fg.view(k).data_ptr() % 16 == 0, k
+        got = fg.view(k).cpu().numpy()
+        assert rel_maxnorm(got, plain[_GRAD_NAMES[k]].reshape(got.shape)) <= 5e-5, k
+    HipSurfel(kw, make_sink=make_sink(True)).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+    for k in _GRAD_NAMES:
+        got = fg.view(k).cpu().numpy()
+        assert rel_maxnorm(got, 2.0 * plain[_GRAD_NAMES[k]].reshape(got.shape)) <= 5e-5, k
+    # a packed buffer WITHOUT padding: shs starts at 3 P floats, misaligned for odd P
+    raw = torch.zeros(59 * P + 8, device="cuda")
+
+    def bad_sink(hip):
+        views, off = {}, 0
+        for k, p in _sink_params(hip).items():
+            views[k] = raw[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        assert views["shs"].data_ptr() % 16 != 0
+        return views, False
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        HipSurfel(kw, make_sink=bad_sink).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
+
+
 def test_pixels_without_contributors_report_zero_median():
     """A sparse scene: most pixels see no surfel at all.  Their median-contributor entry is the reference's float -1
     converted with saturation, i.e. 0 (the C++ conversion is undefined and once compiled to lane garbage)."""

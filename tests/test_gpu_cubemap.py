@@ -64,45 +64,7 @@ def test_cubemap_encoder_module_autograd():
     assert rel_maxnorm(d.grad.cpu().numpy(), rin) <= 1e-4
 
 
-class _OracleCubemap(torch.autograd.Function):
-    """float64 CPU cubemap lookup through the oracle, as an autograd op (checker only)."""
-
-    @staticmethod
-    def forward(ctx, inputs, cubemap, fail):
-        from oracle import oracle as orc
-        out = orc.cubemap_forward(inputs.detach().numpy(), cubemap.detach().numpy(), fail.detach().numpy(), 1, 1, dtype=np.float64)
-        ctx.save_for_backward(inputs, cubemap)
-        return torch.from_numpy(out)
-
-    @staticmethod
-    def backward(ctx, g):
-        from oracle import oracle as orc
-        inputs, cubemap = ctx.saved_tensors
-        gin, gcm, gf = orc.cubemap_backward(g.contiguous().numpy(), inputs.detach().numpy(), cubemap.detach().numpy(), 1, 1, dtype=np.float64)
-        return torch.from_numpy(gin), torch.from_numpy(gcm), torch.from_numpy(gf)
-
-
-def _reference_chain(normal_view, base, strength, cubemap, fail, cam, W, H):
-    """gaussian_renderer/__init__.py:22-35,148,178-179,197-199 + utils/general_utils.py:177-197, float64 on the CPU."""
-    wvt = torch.from_numpy(cam["viewmatrix"]).double()
-    R = torch.from_numpy(cam["R"]).double()
-    T = torch.from_numpy(cam["T"]).double()
-    K = cam["K"].astype(np.float32)
-    rn = normal_view.permute(1, 2, 0) @ (wvt[:3, :3].T)
-    rn = rn / (torch.norm(rn, dim=-1, keepdim=True) + 1e-6)
-    Rw = R.T
-    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing='xy')
-    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
-    pc = torch.tensor(np.dot(xy1, np.linalg.inv(K).T)).double()
-    rays_o = (-Rw.T @ T.unsqueeze(-1)).flatten()
-    pw = (pc - T[None, None]).reshape(-1, 3) @ Rw
-    rd = pw - rays_o[None]
-    rd = (rd / torch.norm(rd, dim=1, keepdim=True)).reshape(H, W, 3)
-    refl = rd - 2 * rn * torch.sum(rd * rn, dim=-1, keepdim=True)
-    col = torch.sigmoid(_OracleCubemap.apply(refl.reshape(-1, 3), cubemap, fail).permute(1, 0))
-    col = col.reshape(H, W, 3).permute(2, 0, 1)
-    final = (1 - strength) * base + strength * col
-    return final, col, rn.permute(2, 0, 1)
+from helpers_chain import OracleCubemap as _OracleCubemap, reference_chain as _reference_chain  # noqa: E402,F401
 
 
 @pytest.mark.parametrize("binned", [True, False])

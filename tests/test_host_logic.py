@@ -99,7 +99,9 @@ def test_flat_grads_views_and_accumulation():
     p = {"a": torch.zeros(5, 3, requires_grad=True), "b": torch.zeros(4, requires_grad=True)}
     fg = FlatGrads(p)
     ((p["a"] * 2).sum() + (p["b"] * 3).sum()).backward()
-    assert fg.flat.numel() == 19 and torch.equal(fg.flat[:15], torch.full((15,), 2.0)) and torch.equal(fg.flat[15:], torch.full((4,), 3.0))
+    # every slice starts on a 16-byte boundary (float4 stores of the backward kernels into sink views): "a" (15 floats) is padded to 16
+    assert fg.slices == {"a": (0, 15), "b": (16, 20)} and fg.flat.numel() == 20
+    assert torch.equal(fg.view("a"), torch.full((5, 3), 2.0)) and torch.equal(fg.view("b"), torch.full((4,), 3.0)) and fg.flat[15] == 0
     ((p["a"] * 1).sum()).backward()                      # accumulates in place into the same buffer
     assert torch.equal(fg.view("a"), torch.full((5, 3), 3.0))
     fg.all_reduce()                                      # no process group: no-op
