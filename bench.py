@@ -38,7 +38,9 @@ for p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+HBM_MEASURED_GBS = 6290.0    # same guide: the float4-copy ceiling measured on this part (SURVEY.md §8d asks for both)
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+DIGEST_FILE = os.path.join(PKG, "csrc", "_obj", "digest.txt")      # written by csrc/build.py: sha256 over every kernel source + flags
 
 
 class Scene:
@@ -113,23 +115,47 @@ def main():
     ap.add_argument("--sync-reflection-tail", action="store_true",
                     help="keep the cubemap-gradient tail of the reflection backward on the main stream (default: side stream, joined by the all-reduce)")
     ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in object (reference entry points with plain autograd)")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="N > 1, full_train_step: reduce-scatter -> Adam on this rank's 1/N of the flat buffer -> all-gather instead of all-reduce -> full Adam")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
 
+    # ---- launcher.  `python bench.py --gpus N` with N > 1 and no torchrun environment starts its N ranks itself, BEFORE this process
+    # makes any GPU call (fresh children through `python -m torch.distributed.run`; a process that has initialised the GPU is never
+    # re-exec'ed), relays rank 0's JSON line and exits with the children's status.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # never report another N than the one asked for (round 2: `--gpus 8` without torchrun silently measured one GPU)
+        if rank == 0:
+            print("bench: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr, flush=True)
+        raise SystemExit(2)
     dist_on = world > 1
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev        # one rank per GPU on a full node; ranks share a GPU only in the gloo rehearsal below
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend, ranks = None, 1
     if dist_on:
         import torch.distributed as dist
         backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only to rehearse N > 1 on one GPU
         if backend == "nccl":
+            if ndev < world:
+                if rank == 0:
+                    print("bench: %d ranks but %d visible GPUs: RCCL needs one GPU per rank (GSR_BENCH_BACKEND=gloo rehearses the N > 1 "
+                          "code path on fewer GPUs)" % (world, ndev), file=sys.stderr, flush=True)
+                raise SystemExit(2)
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        ranks = dist.get_world_size()
+        if ranks != args.gpus:
+            raise SystemExit("bench: process group has %d ranks, --gpus %d" % (ranks, args.gpus))
 
     import gsr_synth as S
     import _gsr
@@ -170,17 +196,26 @@ def main():
     # no autograd accumulation passes.  Then ONE all-reduce, inside the step.  The part of the reflection backward that only
     # produces the cubemap gradient runs on the library's side stream beside the rasterizer backward (async_tail);
     # FlatGrads.all_reduce() makes the step's stream wait for it, so it is inside the timed region.
-    def step_into(buf, reduce):
+    ar_marks = []      # (start, end) event pairs around the all-reduce; filled only in the instrumented pass
+
+    def step_into(buf, reduce, timed=False):
         sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
         for i, view in enumerate(views):
             view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
             means2D.grad = None
             final, allmap = render(view, rsink, i > 0)
             torch.autograd.backward([final, allmap], [g_final, g_allmap])
-        return reduce(buf)
+        if not timed:
+            return reduce(buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = reduce(buf)       # RCCL runs it on its own stream; the step's stream waits for the result, so e1 sees it complete
+        e1.record()
+        ar_marks.append((e0, e1))
+        return out
 
-    def step():
-        step_into(scene.grads, lambda b: b.all_reduce())
+    def step(timed=False):
+        step_into(scene.grads, lambda b: b.all_reduce(), timed)
 
     def sync_all():
         if dist_on:
@@ -202,12 +237,13 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     for i in range(args.steps):
         marks[i].record()
-        step()
+        step(timed=True)
     marks[args.steps].record()
     sync_all()
     stages = _gsr.profile_collect()
     _gsr.profile_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    allreduce_ms = float(np.median([a.elapsed_time(b) for a, b in ar_marks])) if ar_marks else 0.0
 
     # N > 1, labelled extra: the same steps with the all-reduce of step k (RCCL, its own stream) overlapped with step k+1, which
     # renders into a second buffer.  Nothing consumes the reduced gradients in that loop — a training step cannot do this
@@ -268,10 +304,17 @@ def main():
     scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
     full = None if args.no_full_step else full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, world, views_total)
 
+    rank_ms = {"min": round(dt / args.steps * 1e3, 4), "max": round(dt / args.steps * 1e3, 4)}
     if dist_on:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmin = tmax.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dt = float(tmax.item())
+        rank_ms = {"min": round(float(tmin.item()) / args.steps * 1e3, 4), "max": round(dt / args.steps * 1e3, 4)}
+        armax = torch.tensor([allreduce_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(armax, op=dist.ReduceOp.MAX)
+        allreduce_ms = float(armax.item())
     ms_per_step = dt / args.steps * 1e3
     value = views_total * args.steps / dt
 
@@ -290,7 +333,8 @@ def main():
         refl_bytes = (64 + 112) * HW
         pmc = pmc_summary("surfel_render_bwd_rows_kernel", P, W, H)
         roof = {"kernel": "surfel_render_bwd_rows_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc.get("traffic"),
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBS, 4),
+                "measured_ceiling": HBM_MEASURED_GBS, "traffic": pmc.get("traffic"),
                 "traffic_source": pmc.get("source"), "avg_launch_ms": round(launch_s * 1e3, 4), "algorithmic_bytes_per_launch": bytes_bwd}
         if pmc.get("insts_valu"):
             rate = pmc["insts_valu"] / launch_s
@@ -321,7 +365,10 @@ def main():
             "step_algorithmic_GBps": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": roof,
         }
+        out["ranks"] = {"world_size": ranks, "backend": backend or "none", "ms_per_step_per_rank": rank_ms}
         if dist_on:
+            out["nccl_ranks"] = ranks if backend == "nccl" else 0   # dist.get_world_size() of the RCCL process group (0: a gloo rehearsal)
+            out["allreduce_ms"] = round(allreduce_ms, 4)            # median over the instrumented steps, max over ranks, events on the step's stream
             out["allreduce"] = {"payload_MB": round(scene_payload_mb, 1), "inside_step": True,
                                 "overlapped_with_next_step_ms_per_step": None if overlap_ms is None else round(overlap_ms, 4),
                                 "what": "value / ms_per_step: all-reduce inside every step (what a training step pays); the overlapped figure "
@@ -332,12 +379,49 @@ def main():
         if not args.no_c5 and world == 1:
             torch.cuda.empty_cache()
             out["c5"] = c5_object(S, dev)
+        if not args.no_dropin and world == 1:
+            torch.cuda.empty_cache()
+            out["dropin"] = dropin_object(args, S, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(S, P, W, H, args.mu, args.cubemap)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Parent side of `python bench.py --gpus N` (N > 1) outside torchrun: starts `python -m torch.distributed.run --nproc-per-node N` on this
+    very script with the same arguments as a CHILD process (this process has made no GPU call and makes none), passes the children's
+    stderr through, prints rank 0's JSON line once and returns the exit status.  A line whose n_gpus differs from N is an error."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:          # a free rendezvous port on the loopback interface (the container hostname may not resolve)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print("bench: the rank processes exited with status %d" % proc.returncode, file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    if line is None:
+        print("bench: rank 0 printed no result line", file=sys.stderr, flush=True)
+        return 3
+    got = json.loads(line).get("n_gpus")
+    if got != n:
+        print("bench: asked for %d ranks, the result line reports %r" % (n, got), file=sys.stderr, flush=True)
+        return 4
+    print(line, flush=True)
+    return 0
 
 
 def xgmi_model_ms(payload_mb, n):
@@ -361,8 +445,14 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
     scene.release()
     # all learning rates 0: Adam does its full arithmetic and memory traffic but the scene stays the C3 configuration
     # (with real rates the random target image changes opacities/scales within a few steps and the render cost drifts)
-    st = GaussianTrainState(tensors, dev, lrs={k: 0.0 for k in DEFAULT_LRS})
+    sharded = bool(args.sharded_adam and dist_on)
+    rank = int(os.environ.get("RANK", "0"))
+    st = GaussianTrainState(tensors, dev, lrs={k: 0.0 for k in DEFAULT_LRS}, shard=(rank, world) if sharded else None)
     del tensors
+    closer = None
+    if sharded:
+        from gsr_dist import ShardedStep
+        closer = ShardedStep(st)
     fsink, frsink = st.grads.sink(), st.grads.sink(names=("cubemap", "fail"))
     fenv = EnvMap(st.p["cubemap"], st.p["fail"])
     gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
@@ -382,8 +472,11 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
             surf_depth, surf_normal = surface_pass(allmap, view, 0.0)
             loss = photometric_loss(final, gt_image, 0.2) + normal_consistency_loss(rend_normal, surf_normal, 0.05)
             loss.backward()
-        st.grads.all_reduce()
-        st.optimizer.step()
+        if closer is not None:
+            closer.step()               # reduce-scatter -> Adam over this rank's 1/N of the flat buffers -> all-gather of the parameters
+        else:
+            st.grads.all_reduce()
+            st.optimizer.step()
         return loss
 
     for i in range(args.warmup):
@@ -411,11 +504,99 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         fdt = float(tmax.item())
     nv = len(views)
+    n_floats = st.params.total
     return {"ms_per_step": round(fdt / args.steps * 1e3, 4), "views_per_s": round(views_total * args.steps / fdt, 3),
+            "exchange": ("reduce-scatter -> Adam over 1/%d of the flat buffer per rank -> all-gather (--sharded-adam)" % world) if sharded else
+                        ("all-reduce -> the same Adam over all parameters on every rank" if dist_on else "none (one rank)"),
+            # what the two forms of the exchange + optimizer cost by the xGMI model (bytes on the wire are the same; Adam moves 28 B per
+            # parameter at the ~5.7 TB/s the fused kernel reaches): what --sharded-adam changes is the optimizer term
+            "exchange_model_ms": {"all_reduce_then_adam": dict(xgmi_model_ms(n_floats * 4 / 1e6, world), adam=round(n_floats * 28 / 5.7e12 * 1e3, 3)),
+                                  "reduce_scatter_sharded_adam_all_gather": dict(xgmi_model_ms(n_floats * 4 / 1e6, world),
+                                                                                 adam=round(n_floats * 28 / 5.7e12 * 1e3 / world, 3))} if dist_on else None,
             "step_ms": percentiles([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]),
             "what": "the reference's training iteration: render (rasterizer + surface pass + reflection chain) + L1/SSIM and normal-consistency losses + backward + grad all-reduce + fused Adam (59 floats/Gaussian + cubemap), learning rates 0 so the workload stays C3",
             "final_loss": round(float(loss.item()), 6),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * (1 if k == "adam" else nv)), 4) for k, v in fstages.items() if v[1] > 0}}
+
+
+def dropin_object(args, S, dev):
+    """The path a user of the reference gets by switching the imports and nothing else: C3 through `gaussian_renderer.render()` ->
+    l1_loss / ssim / the normal-consistency expression as train.py:144-196 writes them -> `loss.backward()` with PLAIN autograd (no
+    gradient sinks, no asynchronous reflection tail, parameters as ordinary leaf tensors, the environment map a CubemapEncoder module),
+    and render FPS through `render_fast()` timed the way the reference's eval_fps.py:48-59 times it (time.time() around every call,
+    no explicit synchronisation: the call's own num_rendered read-back is the only one) with the synchronised figure beside it."""
+    from cubemapencoder import CubemapEncoder
+    from gaussian_renderer import render, render_fast
+    from utils.loss_utils import l1_loss, ssim
+    P, W, H = args.gaussians, args.width, args.height
+    sc = S.make_scene(P, "S", seed=1003, mu=args.mu)
+    tex, fail = S.make_cubemap(args.cubemap, 3, 1003)
+    cam = S.make_camera(W, H)
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
+    t = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths")}
+    env = CubemapEncoder(output_dim=3, resolution=args.cubemap).to(dev)
+    with torch.no_grad():
+        env.params["Cubemap_texture"].copy_(torch.from_numpy(tex))
+        env.params["Cubemap_failv"].copy_(torch.from_numpy(fail))
+
+    class View:          # what render() reads from a scene.cameras.Camera
+        FoVx, FoVy, image_width, image_height = cam["FoVx"], cam["FoVy"], W, H
+        world_view_transform, full_proj_transform, camera_center = ct["viewmatrix"], ct["projmatrix"], ct["campos"]
+        HWK, R, T, znear, zfar = (H, W, cam["K"]), ct["R"], ct["T"], cam["znear"], cam["zfar"]
+
+    class Pipe:          # arguments.PipelineParams defaults
+        depth_ratio, compute_cov3D_python, convert_SHs_python, debug = 0.0, False, False, False
+
+    class PC:            # what render() reads from a scene.gaussian_model.GaussianModel
+        get_xyz, get_opacity, get_scaling, get_rotation, get_features, get_refl = (t["means3D"], t["opacities"], t["scales"], t["rotations"], t["shs"],
+                                                                                   t["refl_strengths"])
+        active_sh_degree, get_envmap = 3, env
+    bg = torch.zeros(3, device=dev)
+    gt_image = torch.rand(3, H, W, generator=torch.Generator(device="cpu").manual_seed(1003)).to(dev)
+    leaves = list(t.values()) + list(env.parameters())
+
+    def train_step():
+        for x in leaves:
+            x.grad = None
+        pkg = render(View, PC, Pipe, bg)
+        image = pkg["render"]
+        Ll1 = l1_loss(image, gt_image)
+        loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - ssim(image, gt_image))
+        normal_error = (1 - (pkg["rend_normal"] * pkg["surf_normal"]).sum(dim=0))[None]
+        loss = loss + 0.05 * normal_error.mean()
+        loss.backward()
+        return loss
+
+    K, Wm = args.steps, args.warmup
+    for _ in range(Wm):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = train_step()
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / K * 1e3
+    with torch.no_grad():
+        for _ in range(3):
+            render_fast(View, PC, Pipe, bg)
+        torch.cuda.synchronize()
+        n = max(20, K)
+        times = []
+        t1 = time.perf_counter()
+        for _ in range(n):
+            a = time.time()
+            res = render_fast(View, PC, Pipe, bg)
+            rgb = res["render"]                      # (the reference applies its PPISP post-process here; out of scope)
+            times.append(time.time() - a)
+        torch.cuda.synchronize()
+        fps_sync = n / (time.perf_counter() - t1)
+    del t, env, leaves, rgb, res
+    torch.cuda.empty_cache()
+    return {"what": "reference entry points with plain autograd: gaussian_renderer.render() + l1_loss + ssim + normal-consistency expression + "
+                    "loss.backward() (train.py:144-198; no sinks, no async tail, no fused loss), and render_fast() timed as eval_fps.py:48-59",
+            "train_step_ms": round(step_ms, 4), "train_steps_per_s": round(1e3 / step_ms, 2), "final_loss": round(float(loss.item()), 6),
+            "render_fast_fps_eval_fps_method": round(1.0 / float(np.mean(times)), 2), "render_fast_fps_synchronised": round(fps_sync, 2),
+            "render_fast_calls": n}
 
 
 def c5_object(S, dev, steps=5):
@@ -481,15 +662,22 @@ def pmc_summary(kernel, P, W, H):
     from inside the timed process, so they are QUOTED (source says from where); empty when the file is absent or was collected on
     another configuration."""
     if not os.path.exists(PMC_FILE):
-        return {}
+        return {"source": "none: %s is absent" % os.path.relpath(PMC_FILE, ROOT)}
     with open(PMC_FILE) as f:
         d = json.load(f)
     cfg = d.get("_config", {})
     if (cfg.get("P"), cfg.get("W"), cfg.get("H")) != (P, W, H):
-        return {}
+        return {"source": "none: %s was collected on another configuration" % os.path.relpath(PMC_FILE, ROOT)}
+    # the counters belong to ONE build of the kernels: the summary carries the build digest it was taken on (tests/pmc_summary.py) and is
+    # quoted only while the library in this tree has that digest — after a kernel change the old counters are refused, not quoted stale
+    built = open(DIGEST_FILE).read().strip() if os.path.exists(DIGEST_FILE) else None
+    if not cfg.get("digest") or cfg.get("digest") != built:
+        return {"source": "none: %s was collected on build %s, this library is build %s" % (os.path.relpath(PMC_FILE, ROOT), str(cfg.get("digest"))[:12],
+                                                                                           str(built)[:12])}
     for k, v in d.items():
         if kernel in k:
-            out = {"source": "quoted from %s (rocprofv3 --pmc passes of `%s`, %s)" % (os.path.relpath(PMC_FILE, ROOT), cfg.get("cmd", "bench.py"), cfg.get("when", "this round"))}
+            out = {"source": "quoted from %s (rocprofv3 --pmc passes of `%s`, %s, build %s, commit %s)" % (
+                os.path.relpath(PMC_FILE, ROOT), cfg.get("cmd", "bench.py"), cfg.get("when", "this round"), str(cfg.get("digest"))[:12], cfg.get("commit", "?"))}
             if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 out["traffic"] = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
             if "SQ_INSTS_VALU" in v:
@@ -497,7 +685,7 @@ def pmc_summary(kernel, P, W, H):
             if "SQ_INSTS_SALU" in v:
                 out["insts_salu"] = int(v["SQ_INSTS_SALU"])
             return out
-    return {}
+    return {"source": "none: %s has no row for %s" % (os.path.relpath(PMC_FILE, ROOT), kernel)}
 
 
 def cpu_baseline(S, P, W, H, mu, L):

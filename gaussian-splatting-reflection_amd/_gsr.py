@@ -107,6 +107,8 @@ def _load():
     lib.gsr_split_children.argtypes = [c_int, c_int, c_int, P, P, P, P, P, P, P, P]
     lib.gsr_adam_step.restype = c_int
     lib.gsr_adam_step.argtypes = [P, P, P, P, ctypes.c_uint64, ctypes.POINTER(AdamSegment), c_int, c_float, c_float, c_float, c_int, P]
+    lib.gsr_adam_step_range.restype = c_int
+    lib.gsr_adam_step_range.argtypes = lib.gsr_adam_step.argtypes[:-1] + [ctypes.c_uint64, ctypes.c_uint64, P]
     lib.gsr_set_option.restype = c_int
     lib.gsr_set_option.argtypes = [c_char_p, c_int]
     lib.gsr_profile_enable.restype = c_int
@@ -150,7 +152,7 @@ PYBIND = compiled_binding()
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
             "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_deferred_reflection_forward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
-            "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_normal_loss_scratch_floats", "gsr_normal_loss_forward", "gsr_normal_loss_backward", "gsr_adam_step", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
+            "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_normal_loss_scratch_floats", "gsr_normal_loss_forward", "gsr_normal_loss_backward", "gsr_adam_step", "gsr_adam_step_range", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
 
 STAGES = ["preprocess", "scan_readback", "emit_keys", "sort", "tile_ranges", "render_fwd", "render_bwd", "preprocess_bwd", "refl_fwd",

@@ -253,9 +253,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-            unsigned long long n, AdamSegs segs, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2) {
+            unsigned long long first, unsigned long long n, AdamSegs segs, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2) {
 	// (inv_bc1, inv_sqrt_bc2 carry bc1 and sqrt(bc2) themselves: the divisions stay in the kernel, as in torch's addcdiv path)
-	const unsigned long long i4 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4ull;
+	// elements [first, n) of the buffers (first is a multiple of 4): a rank that owns one shard of the flat buffer steps only that
+	const unsigned long long i4 = first + ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4ull;
 	if (i4 >= n) return;
 	if (i4 + 4 <= n) {
 		float4 p = *reinterpret_cast<float4*>(param + i4);
@@ -388,10 +389,15 @@ extern "C" int gsr_ssim_l1_backward(const float* img1, const float* img2, int C,
 	return 0;
 }
 
-extern "C" int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, const gsr_adam_segment* segments,
-                             int num_segments, float beta1, float beta2, float eps, int step, void* stream_) {
+extern "C" int gsr_adam_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, const gsr_adam_segment* segments,
+                                   int num_segments, float beta1, float beta2, float eps, int step, uint64_t range_begin, uint64_t range_end,
+                                   void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (n == 0) return 0;
+	if (range_begin > range_end || range_end > n || (range_begin & 3u) != 0 || (range_end != n && (range_end & 3u) != 0)) {
+		set_error("gsr_adam_step_range: [range_begin, range_end) must lie inside [0, n) with multiples of 4 as bounds");
+		return GSR_E_INVALID;
+	}
 	if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || num_segments < 1 || num_segments > ADAM_MAX_SEG || step < 1) {
 		set_error("gsr_adam_step: invalid argument (NULL buffer, step < 1 or more than 16 segments)");
 		return GSR_E_INVALID;
@@ -416,12 +422,18 @@ extern "C" int gsr_adam_step(float* param, const float* grad, float* exp_avg, fl
 	if (prev != n) { set_error("gsr_adam_step: segments must tile [0, n) in order"); return GSR_E_INVALID; }
 	// bias corrections in double on the host, as Python floats are in torch/optim/adam.py
 	const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-	const unsigned long long nvec = (n + 3) / 4;
+	if (range_begin == range_end) return 0;
+	const unsigned long long nvec = (range_end - range_begin + 3) / 4;
 	{
 		StageTimer st_(GSR_STAGE_ADAM, stream);
-		adam_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, n, s, beta1, beta2, eps, (float)bc1,
-		                                                               (float)sqrt(bc2));
+		adam_kernel<<<(unsigned)((nvec + 255) / 256), 256, 0, stream>>>(param, grad, exp_avg, exp_avg_sq, range_begin, range_end, s, beta1, beta2, eps,
+		                                                               (float)bc1, (float)sqrt(bc2));
 	}
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
+}
+
+extern "C" int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, const gsr_adam_segment* segments,
+                             int num_segments, float beta1, float beta2, float eps, int step, void* stream_) {
+	return gsr_adam_step_range(param, grad, exp_avg, exp_avg_sq, n, segments, num_segments, beta1, beta2, eps, step, 0, n, stream_);
 }

@@ -306,6 +306,13 @@ typedef struct {
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
                   const gsr_adam_segment* segments, int num_segments, float beta1, float beta2, float eps, int step,
                   void* stream);
+/* Extension for the view-parallel step (no reference counterpart): the same update restricted to elements [range_begin, range_end)
+ * of the SAME buffers and segment table (bounds multiples of 4; range_end may equal n).  A rank that received its 1/N of the
+ * summed gradient by reduce-scatter steps only that shard (1/N of the optimizer's traffic and arithmetic) and the parameters are
+ * all-gathered afterwards; gsr_adam_step is this call with the range [0, n). */
+int gsr_adam_step_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                        const gsr_adam_segment* segments, int num_segments, float beta1, float beta2, float eps, int step,
+                        uint64_t range_begin, uint64_t range_end, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-stage device timing (bench.py's roofline leg).  When enabled, every stage launch is bracketed by

@@ -43,6 +43,28 @@ def grad_gate(a, b, rtol=1e-4, floor=1e-6):
     return float((np.abs(a - b) > tol).mean())
 
 
+# n_contrib (per-pixel last / median contributor) flips where alpha or T sits within an ulp of a threshold.  Observed on MI355X (round 3,
+# tests/observed_errors.py): 0 pixels at C1, 1 of 640 000 (S) / 2 of 640 000 (G) at C2, 4 of 2 073 600 at C5, i.e. <= 3.1e-6 of the pixels.
+# Budget = 10x that (the round-2 budget was 1e-4), never less than 2 pixels.
+N_CONTRIB_BUDGET = 3e-5
+
+
+def n_contrib_ok(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return int((a != b).sum()) <= max(2, int(N_CONTRIB_BUDGET * a.size))
+
+
+def assert_image_close(out, ref, tol, what="color", cap=5e-3):
+    """max-abs bound on an image with the same allowance as n_contrib: a pair whose alpha sits within an ulp of 1/255 (or whose T sits at the
+    saturation threshold) is blended on one side and skipped on the other, which moves that pixel by up to alpha * T ~ 4e-3 — at most
+    N_CONTRIB_BUDGET of the pixels (never fewer than 2) may exceed `tol`, none may exceed `cap`."""
+    d = np.abs(np.asarray(out, np.float64) - np.asarray(ref, np.float64))
+    d = d.reshape(-1, d.shape[-2] * d.shape[-1]).max(axis=0)
+    over = int((d > tol).sum())
+    assert over <= max(2, int(N_CONTRIB_BUDGET * d.size)), (what, "pixels over %g" % tol, over, float(d.max()))
+    assert float(d.max()) <= cap, (what, float(d.max()))
+
+
 GATE_BUDGET = 1e-5      # admissible failing fraction of grad_gate (threshold flips of a pixel's contributor list move a few rows)
 
 

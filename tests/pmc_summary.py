@@ -35,7 +35,12 @@ def fold(directories):
 def main():
     out, P, W, H, cmd = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     acc = fold(sys.argv[6:])
-    res = {"_config": {"P": P, "W": W, "H": H, "cmd": cmd, "when": time.strftime("%Y-%m-%d")},
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dig = os.path.join(root, "gaussian-splatting-reflection_amd", "csrc", "_obj", "digest.txt")
+    # which build of the kernels these counters belong to: bench.py quotes them only while the library in the tree has this digest.  The
+    # commit is whatever the caller exports (the GPU box has no .git): GSR_COMMIT=$(git rev-parse --short HEAD) in the gpurun command line.
+    res = {"_config": {"P": P, "W": W, "H": H, "cmd": cmd, "when": time.strftime("%Y-%m-%d"),
+                       "digest": open(dig).read().strip() if os.path.exists(dig) else None, "commit": os.environ.get("GSR_COMMIT", "unrecorded")},
            "_units": "per launch, averaged over launches; FETCH_SIZE / WRITE_SIZE in KB, uncorrected (double FETCH_SIZE on gfx950); SQ_* "
                      "cycle counters in quad-cycles summed over the chip"}
     for k in sorted(acc):

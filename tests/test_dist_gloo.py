@@ -178,3 +178,84 @@ def test_c4_batch_accumulate_then_one_allreduce(tmp_path, world, n_views):
     for j, k in enumerate(sorted(sizes)):
         part = got[off[k]: off[k] + sizes[k]]
         assert torch.all(part == float(tot * (j + 2))), k
+
+
+class _CpuAdam:
+    """CPU stand-in for gsr_train.FlatAdam in the world_size-2 test below (the product optimizer is a HIP kernel; there is no CPU path): the
+    oracle's Adam (test infrastructure) over the optimizer's `owned` range, learning rates expanded from the same segment table."""
+
+    def __init__(self, flat_adam):
+        self.o = flat_adam
+        self.steps = 0
+        total = flat_adam.params.total
+        lr = np.zeros(total, np.float32)
+        for sgm in flat_adam._segments():
+            idx = np.arange(sgm.begin, sgm.end)
+            lr[idx] = sgm.lr if sgm.period == 0 else np.where((idx - sgm.begin) % sgm.period < sgm.split, sgm.lr, sgm.lr2)
+        self.lr = lr
+
+    def step(self):
+        from oracle import oracle as orc
+        self.steps += 1
+        a, b = self.o.owned
+        o = self.o
+        p, m, v = orc.adam(o.params.flat[a:b].detach().numpy(), o.grad[a:b].numpy(), o.exp_avg.numpy(), o.exp_avg_sq.numpy(), self.lr[a:b], step=self.steps)
+        with torch.no_grad():
+            o.params.flat[a:b] = torch.from_numpy(p)
+        o.exp_avg.copy_(torch.from_numpy(m))
+        o.exp_avg_sq.copy_(torch.from_numpy(v))
+
+
+def _sharded_tensors(P):
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return {"means3D": r(P, 3), "shs": r(P, 16, 3), "opacities": r(P, 1), "scales": r(P, 2), "rotations": r(P, 4), "refl_strengths": r(P, 1),
+            "cubemap": r(6, 3, 4, 4), "fail": r(3)}
+
+
+def _sharded_worker(rank, world, port, P, steps, out_dir):
+    """reduce-scatter -> Adam on the rank's shard -> all-gather (gsr_dist.ShardedStep) against all-reduce -> full Adam, three steps."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_dist import ShardedStep
+    from gsr_train import GaussianTrainState
+    st = GaussianTrainState(_sharded_tensors(P), "cpu", shard=(rank, world))
+    assert st.params.total % (4 * world) == 0 and st.optimizer.exp_avg.numel() == st.params.total // world      # 1/N of the moments
+    st.optimizer = _CpuAdam(st.optimizer)
+    sharded = ShardedStep(st)
+    assert sharded.range == (rank * st.params.total // world, (rank + 1) * st.params.total // world)
+    for k in range(steps):
+        gg = torch.Generator().manual_seed(100 * k + rank)
+        st.grads.flat.copy_(torch.randn(st.params.total, generator=gg))      # this rank's accumulated view gradients of step k
+        sharded.step()
+    torch.save(st.params.flat.detach().clone(), os.path.join(out_dir, "sharded_%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduce_scatter_sharded_adam_all_gather_equals_allreduce_adam(tmp_path):
+    P, steps, world = 203, 3, 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_worker, args=(world, port, P, steps, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(str(tmp_path), "sharded_%d.pt" % r), weights_only=True) for r in range(world)]
+    assert torch.equal(got[0], got[1])                                     # every rank ends with the same, complete parameters
+    # serial reference: all-reduce (sum over ranks) then the same Adam over the whole buffer, in one process
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-reflection_amd"))
+    from gsr_train import GaussianTrainState
+    st = GaussianTrainState(_sharded_tensors(P), "cpu", shard=(0, 1))
+    ref = GaussianTrainState(_sharded_tensors(P), "cpu", shard=(0, world))  # (same layout as the ranks': padded to 4 * world)
+    ref.optimizer.owned = (0, ref.params.total)
+    ref.optimizer.exp_avg = torch.zeros(ref.params.total)
+    ref.optimizer.exp_avg_sq = torch.zeros(ref.params.total)
+    cpu = _CpuAdam(ref.optimizer)
+    for k in range(steps):
+        tot = sum(torch.randn(ref.params.total, generator=torch.Generator().manual_seed(100 * k + r)) for r in range(world))
+        ref.grads.flat.copy_(tot)
+        cpu.step()
+    np.testing.assert_allclose(got[0].numpy(), ref.params.flat.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert st.params.total <= ref.params.total < st.params.total + 4 * world
+    assert float((got[0] - ref.params.flat.detach()).abs().max()) < 1e-6 and float((got[0][:P * 3] - _sharded_tensors(P)["means3D"].reshape(-1)).abs().max()) > 0

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GATE_BUDGET, HipSurfel, S, assert_planes_psnr, grad_gate, psnr, rel_maxnorm, scene_kwargs
+from helpers import GATE_BUDGET, HipSurfel, S, assert_planes_psnr, grad_gate, n_contrib_ok, psnr, rel_maxnorm, scene_kwargs
 
 pytestmark = pytest.mark.gpu
 P, W, H = 1_000_000, 1920, 1080
@@ -80,7 +80,7 @@ def test_c3_against_oracle(c3):
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
     nc_h, nc_o = hip.state("n_contrib"), o.state("n_contrib")
-    assert (nc_h != nc_o).mean() <= 1e-4
+    assert n_contrib_ok(nc_h, nc_o)
     assert psnr(out["color"], ref["color"]) >= 50
     assert_planes_psnr(out["allmap"], ref["allmap"])          # every plane against its own peak
     g = S.make_upstream_grads(H, W, 1003)
@@ -105,7 +105,7 @@ def test_full_size_gauss_variant_against_oracle():
     assert out["num_rendered"] == ref["num_rendered"]
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
-    assert (hip.state("n_contrib").astype(np.int64) != o.state("n_contrib").astype(np.int64)).mean() <= 1e-4
+    assert n_contrib_ok(hip.state("n_contrib").astype(np.int64), o.state("n_contrib").astype(np.int64))
     for k in ("color", "normal_map", "invdepth", "refl_strength_map"):
         assert psnr(out[k], ref[k], peak=max(1.0, float(np.abs(ref[k]).max()))) >= 50, k
     g = S.make_upstream_grads(H, W, 1003)
@@ -152,7 +152,7 @@ def test_c5_gauss_5m_antialiasing_inverse_depth_against_oracle():
     assert out["num_rendered"] == ref["num_rendered"] and out["num_rendered"] > 3 * P5
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
-    assert (hip.state("n_contrib").astype(np.int64) != o.state("n_contrib").astype(np.int64)).mean() <= 1e-4
+    assert n_contrib_ok(hip.state("n_contrib").astype(np.int64), o.state("n_contrib").astype(np.int64))
     for k in ("color", "normal_map", "invdepth", "refl_strength_map"):
         assert psnr(out[k], ref[k], peak=max(1.0, float(np.abs(ref[k]).max()))) >= 50, k
     g = S.make_upstream_grads(H, W, 1005)
@@ -181,7 +181,7 @@ def test_c3_rotated_view_and_coloured_background_against_oracle():
     assert out["num_rendered"] == ref["num_rendered"] and (ref["radii"] == 0).mean() > 0.02      # some of the scene is culled
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
-    assert (hip.state("n_contrib") != o.state("n_contrib")).mean() <= 1e-4
+    assert n_contrib_ok(hip.state("n_contrib"), o.state("n_contrib"))
     assert psnr(out["color"], ref["color"]) >= 50
     assert_planes_psnr(out["allmap"], ref["allmap"])
     g = S.make_upstream_grads(H, W, 2024)

@@ -5,12 +5,14 @@ oracle on identical seeded inputs.  Bars (BASELINE.md §4 / north star):
   * gradients within 1e-4 relative: max-norm per tensor AND elementwise (|a-b| <= 1e-4 |b| + 1e-6 max|b|, failing
     fraction <= 1e-5: helpers.grad_gate)
 n_contrib (per-pixel last contributor) depends on exp() ulps through the alpha < 1/255 and T < 1e-4
-thresholds; it is compared with a mismatch budget of 1e-4 of the pixels and documented in DESIGN.md.
+thresholds; it is compared with a mismatch budget of 3e-5 of the pixels (helpers.N_CONTRIB_BUDGET).
+Absolute bounds are ~10x what tests/observed_errors.py measured on MI355X in round 3: colour max-abs 2.8e-6 (S) / 4.8e-5 (G) at C2,
+gaussian_weights 8.6e-7 relative / 1.2e-7 absolute.
 """
 import numpy as np
 import pytest
 
-from helpers import GATE_BUDGET, HipGauss, HipSurfel, S, grad_gate, psnr, rel_maxnorm, scene_kwargs
+from helpers import GATE_BUDGET, HipGauss, HipSurfel, S, assert_image_close, grad_gate, n_contrib_ok, psnr, rel_maxnorm, scene_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -46,16 +48,18 @@ def _run_surfel(P, W, H, seed, mu, sh_degree, bg, mask_radius=0.0, backward=True
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     _check_binning(hip, o)
     nc_h, nc_o = hip.state("n_contrib").astype(np.uint32), o.state("n_contrib")
-    assert (nc_h[0] != nc_o[0]).mean() <= 1e-4
-    assert (nc_h[1] != nc_o[1]).mean() <= 1e-4
+    assert n_contrib_ok(nc_h[0], nc_o[0]) and n_contrib_ok(nc_h[1], nc_o[1])
     assert psnr(out["color"], ref["color"]) >= PSNR_MIN
-    assert np.abs(out["color"] - ref["color"]).max() < 2e-3
+    assert_image_close(out["color"], ref["color"], 3e-5)
     assert psnr(out["refl_strength_map"], ref["refl_strength_map"]) >= PSNR_MIN
     for plane in range(8):
         scale = max(1.0, float(np.abs(ref["allmap"][plane]).max()))
         assert psnr(out["allmap"][plane], ref["allmap"][plane], peak=scale) >= PSNR_MIN, plane
     # gaussian_weights: true max in both; tolerance for exp() ulps
-    np.testing.assert_allclose(out["gaussian_weights"], ref["gaussian_weights"], rtol=2e-3, atol=1e-5)
+    gw_h, gw_o = out["gaussian_weights"].astype(np.float64), ref["gaussian_weights"].astype(np.float64)
+    gw_bad = np.abs(gw_h - gw_o) > 1.5e-6 + 1e-5 * np.abs(gw_o)
+    # (a surfel whose maximum comes from a pair sitting on the alpha = 1/255 threshold may differ by its whole weight, <= 1/255: same budget as n_contrib)
+    assert int(gw_bad.sum()) <= max(2, int(3e-5 * gw_o.size)) and np.abs(gw_h - gw_o).max() <= 5e-3, (int(gw_bad.sum()), np.abs(gw_h - gw_o).max())
     if not backward:
         return
     g = S.make_upstream_grads(H, W, seed)
@@ -80,11 +84,11 @@ def _run_gauss(P, W, H, seed, mu, sh_degree, bg, antialiasing=False, backward=Tr
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     _check_binning(hip, o)
     nc_h, nc_o = hip.state("n_contrib").astype(np.uint32)[0], o.state("n_contrib")
-    assert (nc_h != nc_o).mean() <= 1e-4
+    assert n_contrib_ok(nc_h, nc_o)
     for k in ("color", "normal_map", "refl_strength_map", "invdepth"):
         scale = max(1.0, float(np.abs(ref[k]).max()))
         assert psnr(out[k], ref[k], peak=scale) >= PSNR_MIN, k
-    assert np.abs(out["color"] - ref["color"]).max() < 2e-3
+    assert_image_close(out["color"], ref["color"], 5e-4)
     if not backward:
         return
     g = S.make_upstream_grads(H, W, seed)

@@ -1,5 +1,8 @@
 """Host-side logic of the drop-in packages that runs without a GPU: argument validation mirrors the reference's
 wrappers (same exceptions, same messages), settings tuples have the reference's fields, synthetic data is seeded."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -107,3 +110,14 @@ def test_flat_grads_views_and_accumulation():
     fg.all_reduce()                                      # no process group: no-op
     fg.zero_()
     assert float(fg.flat.abs().sum()) == 0 and p["a"].grad.data_ptr() == fg.flat.data_ptr()
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """bench.py: `--gpus 4` inside a torchrun environment of another size exits with status 2 before any GPU call (runs here, without a GPU);
+    round 2's bench silently measured one GPU in that situation."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    assert p.returncode == 2 and "--gpus 4" in p.stderr and "WORLD_SIZE=2" in p.stderr and not p.stdout.strip()
