@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s mea
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 HBM_MEASURED_GBS = 6290.0    # same guide: the float4-copy ceiling measured on this part (SURVEY.md §8d asks for both)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_FILE_C5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_summary.json")
 DIGEST_FILE = os.path.join(PKG, "csrc", "_obj", "digest.txt")      # written by csrc/build.py: sha256 over every kernel source + flags
 
 
@@ -115,6 +116,7 @@ def main():
     ap.add_argument("--sync-reflection-tail", action="store_true",
                     help="keep the cubemap-gradient tail of the reflection backward on the main stream (default: side stream, joined by the all-reduce)")
     ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
+    ap.add_argument("--only-c5", action="store_true", help="run only the C5 object (5e6 Gaussians, variant G) and print it: the command the C5 rocprofv3 passes wrap")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in object (reference entry points with plain autograd)")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1, full_train_step: reduce-scatter -> Adam on this rank's 1/N of the flat buffer -> all-gather instead of all-reduce -> full Adam")
@@ -161,6 +163,12 @@ def main():
     import _gsr
     from gaussian_renderer import deferred_reflection
     from gsr_dist import shard_views
+
+    if args.only_c5:
+        if world != 1:
+            raise SystemExit("bench: --only-c5 is a single-GPU run")
+        print(json.dumps(c5_object(S, dev, steps=max(5, args.steps))), flush=True)
+        return
 
     if os.environ.get("GSR_DEV"):
         _gsr.set_option("dev", int(os.environ["GSR_DEV"], 0))   # development ablations only (tests/ablate.py)
@@ -647,15 +655,17 @@ def c5_object(S, dev, steps=5):
     for name, key, nbytes in (("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P), ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW)):
         if stage.get(key):
             gbs = nbytes / (stage[key] * 1e-3) / 1e9
+            pmc = pmc_summary(name, P, W, H, PMC_FILE_C5)
             kernels[name] = {"bound": "hbm", "avg_launch_ms": stage[key], "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "frac_of_measured_ceiling": round(gbs / HBM_MEASURED_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source")}
     del t, means2D
     torch.cuda.empty_cache()
     return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd", "num_rendered": R[0],
             "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps, "stage_ms_per_step": stage, "kernel_sum_ms": round(sum(stage.values()), 4), "roofline": kernels}
 
 
-def pmc_summary(kernel, P, W, H):
+def pmc_summary(kernel, P, W, H, PMC_FILE=PMC_FILE):
     """Per-launch counters of `kernel` from the committed PMC passes of this same command (profiles/r02_pmc_summary.json, written
     by tests/pmc_summary.py from separate `rocprofv3 --pmc ... --kernel-trace` runs on the GPU box).  FETCH_SIZE / WRITE_SIZE are in
     KB; FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64, MI355X_MICROARCH.md HBM section).  The counters cannot be read

@@ -11,7 +11,6 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include "gsr_sort.hpp"
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
@@ -90,12 +89,26 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 // 1024 x 4 measured best (whole two-level sort at P = 1 M, ms: tuned 0.274, 256x8 0.270, 512x4 0.251, 1024x2 0.250,
 // 1024x3 0.233, 1024x4 0.220, 1024x6 0.251, 1024x8 0.235; it also wins at 0.3 M, 2 M and 5 M).  The second-level sort of
 // R tile ids keeps the tuned 1024 x 16 (1024x4 0.240, 1024x8 0.226, 512x8 0.258 against 0.220).
-#ifndef DEPTH_SORT_SHAPE
-#define DEPTH_SORT_SHAPE 1024, 4, 8
+#ifndef DEPTH_SORT_BS
+#define DEPTH_SORT_BS 1024
 #endif
-#ifndef TILE_SORT_SHAPE
-#define TILE_SORT_SHAPE 1024, 16, 8
+#ifndef DEPTH_SORT_IPT
+#define DEPTH_SORT_IPT 4
 #endif
+#define DEPTH_SORT_SHAPE DEPTH_SORT_BS, DEPTH_SORT_IPT, 8
+#define DEPTH_KEY_BITS 31u             // depths are positive floats (culled Gaussians carry FLT_MAX): their bit patterns order like the values
+#define DEPTH_KEY_PLACES 4u            // 8-bit digits
+// (Round 3, measured and dropped: keys = float bits minus the bits of the near plane have 27 significant bits for every depth below 13 107,
+// i.e. three 9-bit places instead of four 8-bit ones, with a host-side fallback to the 31-bit sort for scenes that reach beyond.  A 9-bit
+// pass over 1 M pairs takes 29 us against 17.7 us for an 8-bit one — the ranking works bit by bit and its LDS counters double — so three of
+// them cost more than four: depth passes 86 vs 71 us at C3, the same at C5.)
+#ifndef TILE_SORT_IPT
+#define TILE_SORT_IPT 16
+#endif
+#ifndef TILE_SORT_BITS
+#define TILE_SORT_BITS 8
+#endif
+#define TILE_SORT_SHAPE 1024, TILE_SORT_IPT, TILE_SORT_BITS
 static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
 
 // tiles_touched read through the depth order: element i of the sequence the second scan runs over
@@ -105,25 +118,19 @@ struct TouchedInOrder {
 };
 // bytes of the P-sized temp region: the two scans share the first part, the depth pre-sort has the second one to itself
 // (its look-back state is cleared by the preprocess kernel, before the first scan runs)
-// tiles_touched widened to 64 bits: num_rendered is their sum, and a 32-bit sum would wrap silently at 2^32 instances
-struct Widen {
-	__host__ __device__ unsigned long long operator()(uint32_t v) const { return (unsigned long long)v; }
-};
 static size_t scan_part_bytes(size_t P) {
-	size_t a = 0, b = 0, c = 0;
+	size_t a = 0, b = 0;
 	(void)rocprim::inclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
 	auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TouchedInOrder{nullptr});
 	(void)rocprim::inclusive_scan(nullptr, b, it, (uint32_t*)nullptr, P, rocprim::plus<uint32_t>(), 0, false);
-	auto wide = rocprim::make_transform_iterator((const uint32_t*)nullptr, Widen{});
-	(void)rocprim::reduce(nullptr, c, wide, (unsigned long long*)nullptr, 0ull, P, rocprim::plus<unsigned long long>(), 0, false);
-	return (std::max(std::max(a, b), c) + 255) & ~(size_t)255;
+	return (std::max(a, b) + 255) & ~(size_t)255;
 }
 // temp bytes: the larger of the two drivers' needs, so that the runtime switch (option_sort_driver) never changes a workspace size
 static size_t depth_sort_bytes(size_t P) {
 	size_t c = 0, d = 0;
 	if (P <= SORT_MAX_ITEMS)
 		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-		                                            (uint32_t*)nullptr, P, 0u, 31u, 0);
+		                                            (uint32_t*)nullptr, P, 0u, DEPTH_KEY_BITS, 0);
 	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
 	                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
 	return std::max(c, d);
@@ -160,7 +167,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.scan_temp_bytes = scan_bytes;
 	g.depth_sort_temp = g.scan_temp ? static_cast<char*>(g.scan_temp) + scan_part_bytes(P) : nullptr;
 	g.depth_sort_bytes = depth_sort_bytes(P);
-	g.depth_sort_clear = P <= SORT_MAX_ITEMS ? onesweep_cleared_bytes<DEPTH_SORT_SHAPE>(P, 0u, 31u) : 0;
+	g.depth_sort_clear = P <= SORT_MAX_ITEMS ? onesweep_cleared_bytes<DEPTH_SORT_SHAPE>(P, 0u, DEPTH_KEY_BITS) : 0;
 	if (total) *total = c.size();
 	return g;
 }
@@ -201,6 +208,49 @@ BinningState carve_binning(void* buf, size_t R, size_t tiles, size_t sort_bytes,
 // (A wave-cooperative version — the 64 Gaussians of a wave own one contiguous output run; lanes take instances begin + l,
 // + 64, ..., find the owner by bisection over the start offsets in LDS and store 256 contiguous bytes per instruction —
 // was measured slower: 75 us against 57 us at R = 3.9 M.)
+// Per-Gaussian statistics between preprocess and the sorts, ONE dispatch (round 3; it replaces rocPRIM's 64-bit reduce of tiles_touched
+// and the histogram dispatch of the depth sort):
+//   * num_rendered = sum of tiles_touched in 64 bits (the reference's 32-bit InclusiveSum, rasterizer_impl.cu:282, wraps silently),
+//   * the counts of the four 8-bit digits of the depth keys (per-workgroup LDS histogram, non-zero bins flushed with global atomics: what
+//     rocPRIM's onesweep_histograms does), laid out as the sort's pass kernels expect them.
+// flags[2,3] were zeroed by the preprocess kernel, depth_counts by its clear of the depth sort's temp region.
+// (The same fold was tried for the tile-id sort — emit_tiles_kernel counting the digits of the ids it writes in an LDS histogram — and
+// lost: the high digit of a tile id has 32 values, the 64 lanes of a wave hit the same few bins and LDS atomics serialise; key emission went
+// from 0.044 to 0.114 ms at C3 and from 0.12 to 0.38 ms at C5 to save an 8-us dispatch.  The depth keys' low digits are spread over 256 bins.)
+#define STATS_BLOCK 1024
+__global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, const float* __restrict__ depths, const uint32_t* __restrict__ tiles_touched,
+                                                                      uint32_t* __restrict__ depth_counts, int* __restrict__ flags) {
+	__shared__ uint32_t s_hist[DEPTH_KEY_PLACES * 256u];
+	__shared__ unsigned long long s_sum[STATS_BLOCK / 64];
+	const uint32_t t = threadIdx.x;
+	s_hist[t] = 0u;                       // (STATS_BLOCK == DEPTH_KEY_PLACES * 256)
+	__syncthreads();
+	unsigned long long sum = 0ull;
+	for (size_t i = (size_t)blockIdx.x * STATS_BLOCK + t; i < (size_t)P; i += (size_t)gridDim.x * STATS_BLOCK) {
+		sum += tiles_touched[i];
+		if (depth_counts != nullptr) {
+			const uint32_t key = __float_as_uint(depths[i]);
+			atomicAdd(&s_hist[key & 255u], 1u);
+			atomicAdd(&s_hist[256u + ((key >> 8) & 255u)], 1u);
+			atomicAdd(&s_hist[512u + ((key >> 16) & 255u)], 1u);
+			atomicAdd(&s_hist[768u + ((key >> 24) & 127u)], 1u);      // (bit 31 is outside the sorted range)
+		}
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+	if ((t & 63u) == 0u) s_sum[t >> 6] = sum;
+	__syncthreads();
+	if (t == 0u) {
+		for (uint32_t w = 1; w < STATS_BLOCK / 64; w++) sum += s_sum[w];
+		if (sum != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), sum);
+	}
+	if (depth_counts != nullptr) {
+		const uint32_t h = s_hist[t];
+		if (h != 0u) atomicAdd(&depth_counts[t], h);
+	}
+}
+static_assert(STATS_BLOCK == DEPTH_KEY_PLACES * 256u, "one histogram bin per thread");
+
 #define EMIT_BIG 8u   // a Gaussian with more instances than this is emitted by its whole wave (C3: 32 -> 0.046 ms, 16 -> 0.045, 8 -> 0.042)
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
@@ -359,19 +409,19 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	Readback* rb = readback_slot();
 	if (!rb) { set_error("pinned word / event for the num_rendered readback could not be created"); return GSR_E_HIP; }
 	int* host = rb->word;
+	const bool own_depth_sort = option_sort_driver() && (size_t)P <= SORT_MAX_ITEMS;
 	{
 		StageTimer st_(GSR_STAGE_SCAN, stream);
 		// num_rendered = sum of tiles_touched, reduced in 64 bits (the reference's 32-bit InclusiveSum, rasterizer_impl.cu:282,
 		// wraps silently at 2^32 instances; its per-Gaussian offsets are not needed here: the instances are emitted in depth
 		// order from the second scan below, and gsr_debug_fetch("point_offsets") computes them on demand)
-		size_t tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));   // the scans' part
-		unsigned long long* total = reinterpret_cast<unsigned long long*>(geom.flags + 2);
-		auto wide = rocprim::make_transform_iterator((const uint32_t*)geom.tiles_touched, Widen{});
-		GSR_HIP_CHECK(rocprim::reduce(geom.scan_temp, tmp, wide, total, 0ull, (size_t)P, rocprim::plus<unsigned long long>(), stream, false));
-		if (debug) GSR_HIP_CHECK(hipStreamSynchronize(stream));
-		GSR_HIP_CHECK(hipMemcpyAsync(host + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		host[1] = 0;
-		if (prefiltered) GSR_HIP_CHECK(hipMemcpyAsync(host + 1, geom.flags, sizeof(int), hipMemcpyDeviceToHost, stream));   // the trap flag is only ever set then
+		// one dispatch: the 64-bit sum and the depth keys' digit counts (gaussian_stats_kernel)
+		const unsigned blocks = (unsigned)std::min<size_t>(512, ((size_t)P + 4 * STATS_BLOCK - 1) / (4 * STATS_BLOCK));
+		gaussian_stats_kernel<<<blocks, STATS_BLOCK, 0, stream>>>(P, geom.depths, geom.tiles_touched,
+		                                                          own_depth_sort ? reinterpret_cast<uint32_t*>(geom.depth_sort_temp) : nullptr, geom.flags);
+		GSR_LAUNCH_CHECK(debug, stream);
+		// flags[2,3] num_rendered; flags[0] (the trap flag) is only ever set, and cleared, with `prefiltered`
+		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
 	}
 	// the host waits on THIS point only, not on the level-1 work enqueued behind it
 	hipEvent_t readback_done = rb->done;
@@ -382,9 +432,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// tiles_touched taken in that order
 		StageTimer st_(GSR_STAGE_SORT, stream);
 		size_t tmp = geom.depth_sort_bytes;
-		if (option_sort_driver() && (size_t)P <= SORT_MAX_ITEMS)   // look-back state already cleared by the preprocess kernel
+		if (own_depth_sort)   // look-back state cleared by the preprocess kernel, digit counts accumulated by gaussian_stats_kernel: four dispatches
 			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
-			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, true));
+			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, DEPTH_KEY_BITS, stream, true,
+			                                                   reinterpret_cast<const uint32_t*>(geom.depth_sort_temp)));
 		else
 			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
@@ -396,7 +447,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	GSR_HIP_CHECK(hipEventSynchronize(readback_done));
 	unsigned long long total64;
 	memcpy(&total64, host + 2, sizeof(total64));
-	if (host[1] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
+	if (prefiltered && host[0] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
 	if (total64 > 0x7fffffffull) { set_error("num_rendered = %llu does not fit the int the API returns", total64); return GSR_E_INVALID; }
 	const int R = (int)total64;
 	const uint32_t tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;

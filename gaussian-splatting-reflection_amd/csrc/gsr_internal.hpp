@@ -84,13 +84,15 @@ struct GeomState {
 	                         //          about (ex,ey) united with a disc; see cull_hit() below
 	float* aux;              // G: cov3D P*6.  S: unused
 	float* acc;              // backward accumulator P*ACC_F (zeroed by backward)
-	int* flags;              // 4 ints: [0] prefiltered-trap flag
+	int* flags;              // 4 ints: [0] prefiltered-trap flag, [2,3] num_rendered (64 bits): zeroed by the preprocess kernel, accumulated by
+	                         //         gaussian_stats_kernel
 	uint32_t* depth_sorted;  // P        depth bits in ascending order (output of the depth pre-sort; keys only)
 	uint32_t* order;         // P        Gaussian index at each position of the depth order (stable: ties by index)
 	uint32_t* offsets_sorted;// P        inclusive scan of tiles_touched taken in depth order
 	void* scan_temp;         // temp of the two scans (shared) followed by the temp of the P-sized depth sort
 	size_t scan_temp_bytes;
-	void* depth_sort_temp;   // = scan_temp + scan part; its first depth_sort_clear bytes are zeroed by the preprocess kernel
+	void* depth_sort_temp;   // = scan_temp + scan part; its first depth_sort_clear bytes are zeroed by the preprocess kernel (they start with
+	                         //   the digit counts of the depth sort, which gaussian_stats_kernel then accumulates)
 	size_t depth_sort_bytes, depth_sort_clear;
 };
 struct ImageState {

@@ -5,15 +5,17 @@
 // histograms: 3 dispatches per pass.  A dispatch costs ~5 us on this part whatever it does, and the sorts of this library
 // are small enough (1-4 M pairs) to be bound by exactly that: the eight passes of a training step carried 17 fills.  This
 // driver gives every pass its own look-back states and block-id counter inside one temp region and clears the region once;
-// the device code is rocPRIM's own (rocprim::detail::onesweep_histograms / onesweep_scan_histograms / onesweep_iteration,
-// header-only, ROCm 7.2), instantiated with a fixed workgroup shape instead of the architecture dispatch.
+// the device code is rocPRIM's own (rocprim::detail::onesweep_histograms / onesweep_iteration, header-only, ROCm 7.2), instantiated
+// with a fixed workgroup shape instead of the architecture dispatch.  Round 3: the per-place scan of the digit histograms is done by
+// every workgroup of a pass in LDS (no scan dispatch), and a caller that has the keys in its hands in an earlier kernel can supply
+// the digit counts itself (no histogram dispatch): a sort is then exactly one dispatch per digit place.
 // Stable, ascending, keys compared on bits [begin_bit, end_bit).
 // (Folding the histogram scans into the histogram kernel's last workgroup — ticket counter + __threadfence, the classic
 // "last block" pattern — was measured and is far slower: 0.30 ms against 0.185 ms for the two-level sort.  An agent-scope
 // release fence writes back and invalidates the XCD's L2 on this multi-die part, once per workgroup.)
 //
 // What this file assumes about rocPRIM's PRIVATE device code, and how each assumption is guarded:
-//   * the signatures of detail::onesweep_histograms / onesweep_scan_histograms / onesweep_iteration and of block_id_wrapper:
+//   * the signatures of detail::onesweep_histograms / onesweep_iteration and of block_id_wrapper:
 //     checked by the compiler; the driver is only compiled for the rocPRIM release it was written against
 //     (GSR_ONESWEEP_DRIVER below), any other release takes the public rocprim::radix_sort_pairs for every sort;
 //   * an all-zero onesweep_lookback_state means "empty" and is 4 bytes: static_asserts below;
@@ -48,16 +50,36 @@ __global__ void __launch_bounds__(BS) sort_histogram_kernel(const uint32_t* keys
                                                              unsigned begin_bit, unsigned end_bit) {
 	rocprim::detail::onesweep_histograms<BS, IPT, BITS, false>(keys, digit_counts, size, full_blocks, rocprim::identity_decomposer{}, begin_bit, end_bit);
 }
-template <unsigned BS, unsigned BITS>
-__global__ void __launch_bounds__(BS) sort_scan_histograms_kernel(SortOffset* digit_offsets) {
-	rocprim::detail::onesweep_scan_histograms<BS, BITS>(digit_offsets);
-}
+// One digit pass.  `digit_counts` are the RAW digit counts of this place (what the histogram kernel — or whoever accumulated them, see
+// onesweep_sort_pairs — left): every workgroup turns them into exclusive offsets itself, in LDS (2^BITS <= BS values: one wave-level
+// scan and one cross-wave step), instead of a separate one-workgroup-per-place scan kernel in front of the passes.  A dispatch costs
+// ~5 us on this part whatever it does and these sorts are launch-latency-bound; 256 or 512 redundant adds per workgroup are free.
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
 __global__ void __launch_bounds__(BS) sort_pass_kernel(const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, unsigned size,
-                                                        SortOffset* digit_offsets_in, SortOffset* digit_offsets_out, SortLookback* lookback, unsigned bit,
+                                                        const SortOffset* digit_counts, SortOffset* digit_offsets_out, SortLookback* lookback, unsigned bit,
                                                         unsigned current_bits, unsigned full_blocks, SortBlockId block_id) {
+	constexpr unsigned radix = 1u << BITS;
+	static_assert(radix <= BS && BS % 64 == 0 && BS <= 1024, "one digit per thread");
+	__shared__ SortOffset s_offsets[radix];
+	__shared__ SortOffset s_wave_total[BS / 64];
+	{
+		const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+		const SortOffset mine = t < radix ? digit_counts[t] : 0u;
+		SortOffset incl = mine;
+#pragma unroll
+		for (unsigned off = 1; off < 64; off <<= 1) {
+			const SortOffset o = __shfl_up(incl, off, 64);
+			if (lane >= off) incl += o;
+		}
+		if (lane == 63) s_wave_total[wave] = incl;
+		__syncthreads();
+		SortOffset base = 0;
+		for (unsigned w = 0; w < wave; w++) base += s_wave_total[w];
+		if (t < radix) s_offsets[t] = base + incl - mine;
+		__syncthreads();
+	}
 	rocprim::detail::onesweep_iteration<BS, IPT, BITS, false, rocprim::block_radix_rank_algorithm::match>(
-	    keys_in, keys_out, values_in, values_out, size, digit_offsets_in, digit_offsets_out, lookback, rocprim::identity_decomposer{}, bit, current_bits,
+	    keys_in, keys_out, values_in, values_out, size, s_offsets, digit_offsets_out, lookback, rocprim::identity_decomposer{}, bit, current_bits,
 	    full_blocks, block_id);
 }
 
@@ -82,9 +104,12 @@ __device__ __forceinline__ void sort_clear_region(void* ptr, size_t bytes, size_
 }
 
 // temp == nullptr: returns the required bytes in `bytes` and does nothing else.  size < 2^30.
+// ext_counts != nullptr: the raw digit counts — 2^BITS per place, place p counting digit (key >> (begin_bit + p * BITS)) & (2^BITS - 1)
+// over ALL `size` keys — have already been accumulated there by a kernel that had the keys in its hands anyway (the per-Gaussian
+// statistics kernel for the depth keys, key emission for the tile ids): no histogram dispatch.
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
 hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, size_t size_,
-                               unsigned begin_bit, unsigned end_bit, hipStream_t stream, bool pre_cleared = false) {
+                               unsigned begin_bit, unsigned end_bit, hipStream_t stream, bool pre_cleared = false, const SortOffset* ext_counts = nullptr) {
 	static_assert(sizeof(Value) == 4, "4-byte values");
 	constexpr unsigned radix = 1u << BITS, items_per_block = BS * IPT;
 	if (size_ >= ((size_t)1 << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
@@ -116,8 +141,11 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 		hipError_t e = hipMemsetAsync(base, 0, cleared, stream);
 		if (e != hipSuccess) return e;
 	}
-	sort_histogram_kernel<BS, IPT, BITS><<<blocks, BS, 0, stream>>>(keys_in, digits, size, full_blocks, begin_bit, end_bit);
-	sort_scan_histograms_kernel<BS, BITS><<<places, BS, 0, stream>>>(digits);
+	const SortOffset* counts = ext_counts;
+	if (counts == nullptr) {
+		sort_histogram_kernel<BS, IPT, BITS><<<blocks, BS, 0, stream>>>(keys_in, digits, size, full_blocks, begin_bit, end_bit);
+		counts = digits;
+	}
 
 	bool to_output = (places - 1) % 2 == 0, from_input = true;
 	unsigned place = 0;
@@ -125,7 +153,7 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 		const unsigned current_bits = (end_bit - bit) < BITS ? (end_bit - bit) : BITS;
 		SortLookback* lookback = reinterpret_cast<SortLookback*>(base + o_lookback + lookback_pass * place);
 		SortBlockId block_id = SortBlockId::create(base + o_ids + (size_t)place * 64);
-		SortOffset* d_in = digits + (size_t)place * radix;
+		const SortOffset* d_in = counts + (size_t)place * radix;
 		uint32_t* k_out = to_output ? keys_out : keys_tmp;
 		Value* v_out = to_output ? values_out : values_tmp;
 		if (from_input) {
@@ -147,7 +175,8 @@ template <unsigned BS, unsigned IPT, unsigned BITS>
 size_t onesweep_cleared_bytes(size_t, unsigned, unsigned) { return 0; }
 __device__ __forceinline__ void sort_clear_region(void*, size_t, size_t, size_t) {}
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
-hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t*, uint32_t*, ValuesIn, Value*, size_t, unsigned, unsigned, hipStream_t, bool = false) {
+hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t*, uint32_t*, ValuesIn, Value*, size_t, unsigned, unsigned, hipStream_t, bool = false,
+                               const unsigned* = nullptr) {
 	if (temp == nullptr) bytes = 0;
 	return hipErrorNotSupported;
 }

@@ -242,6 +242,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	if (idx == 0) { g.flags[2] = 0; g.flags[3] = 0; }   // num_rendered (64 bits): accumulated by gaussian_stats_kernel
 	__shared__ float4 s_out[4][S_REC_F4 * 65];
 	const int lane = threadIdx.x & 63;
 	float4* so = s_out[threadIdx.x >> 6];
@@ -301,6 +302,12 @@ struct SurfelRec {
 #define CULL_PAD 0.05f    // the wave's pixel block is padded by this much in the footprint vote (the cull record itself is already dilated by half a pixel)
 #ifndef GSR_BWD_WPE
 #define GSR_BWD_WPE 4
+#endif
+#ifndef GSR_BWD_LIST
+#define GSR_BWD_LIST 1      // 1: rows read their next entry from an LDS list (render_bwd 0.747 -> 0.732 ms at C3); 0: rows walk their bit masks (round 2)
+#endif
+#ifndef GSR_BWD_UNROLL
+#define GSR_BWD_UNROLL 1
 #endif
 #ifdef GSR_FWD_WPE
 #define GSR_FWD_ATTR __attribute__((amdgpu_waves_per_eu(GSR_FWD_WPE, GSR_FWD_WPE)))
@@ -739,6 +746,9 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 	__shared__ float4 s_rec[S_WBATCH * S_REC_F4];       // records of the batch's blended entries (indexed by position in the batch)
 	__shared__ uint32_t s_cw[S_WBATCH];                 // per entry of the chunk (compacted): the slab slot of each of the four rows, one byte each
 	__shared__ uint32_t s_cid[S_WBATCH];                // its surfel id
+#if GSR_BWD_LIST
+	__shared__ uint8_t s_list[4 * S_WBATCH];            // per row: the batch positions of its entries in the order it visits them (last first)
+#endif
 
 	SurfelBwdPix st;
 	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
@@ -805,20 +815,39 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 				const int k = __popcll(call & lt);
 				s_cw[k] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
 				s_cid[k] = id;
+#if GSR_BWD_LIST
+				// the row's visiting order is its slab-slot order: entry number (slot - first slot of the row) of row r is this position
+				if ((c0 >> lane) & 1ull) s_list[s0] = (uint8_t)lane;
+				if ((c1 >> lane) & 1ull) s_list[S_WBATCH + s1 - n0] = (uint8_t)lane;
+				if ((c2 >> lane) & 1ull) s_list[2 * S_WBATCH + s2 - n0 - n1] = (uint8_t)lane;
+				if ((c3 >> lane) & 1ull) s_list[3 * S_WBATCH + s3 - n0 - n1 - n2] = (uint8_t)lane;
+#endif
 			}
 			__syncthreads();
 			// ---- 3. differentiate: every row takes the LAST remaining entry of its own mask.  The mask is kept bit-reversed so that
 			// "last entry" is the lowest set bit (v_ffbl) and dropping it is x & (x - 1).
+#if !GSR_BWD_LIST
 			unsigned long long left = __builtin_bitreverse64(row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : c3)));
+#else
+			// (round 3) the row reads its next entry from the list the staging lanes wrote (one ds_read_u8) instead of walking its bit mask
+			// (two v_ffbl, a 64-bit x & (x - 1), min / sub / or: 11 VALU instructions per iteration in a loop bound by VALU issue)
+			const int nrow = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
+			const uint8_t* mylist = s_list + row * S_WBATCH;
+#endif
 			// byte offset of the row's next slab slot
 			uint32_t myslot = (uint32_t)(row == 0 ? 0 : (row == 1 ? n0 : (row == 2 ? n0 + n1 : n0 + n1 + n2))) * (S_ACC_F * 4u) + slab_lane;
-#pragma unroll 1
+#pragma unroll GSR_BWD_UNROLL
 			for (int t = 0; t < nmax; t++) {
+#if !GSR_BWD_LIST
 				const uint32_t lo = (uint32_t)left, hi = (uint32_t)(left >> 32);
 				const lmask valid = LMASK((lo | hi) != 0u);
 				const uint32_t tz = min(ffbl_raw(lo), ffbl_raw(hi) | 32u);   // count of trailing zeros; garbage if left == 0
 				const uint32_t j = selmu(valid, 63u - tz, jany);
 				left &= left - 1ull;
+#else
+				const lmask valid = LMASK(t < nrow);
+				const uint32_t j = selmu(valid, (uint32_t)mylist[min(t, S_WBATCH - 1)], jany);
+#endif
 				const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + __umul24(j, S_REC_F4 * 16u));   // (24-bit multiply: full rate)
 				const SurfelRec R{q[0], q[1], q[2], q[3], q[4]};
 				float v[S_ACC_F];

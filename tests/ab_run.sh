@@ -8,7 +8,8 @@ for lib in gaussian-splatting-reflection_amd/libgsr_hip.so gaussian-splatting-re
   GSR_BINDING=ctypes GSR_LIB=$PWD/$lib timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-step "$@" 2>>gpurun_out/ab.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-print('ms/step %.4f fwd_ms %.4f' % (d['ms_per_step'], d['forward_ms']), {k:v for k,v in d['stage_ms_per_view'].items() if 'render' in k or 'preprocess' in k or 'sort' in k or 'refl' in k})
+print('ms/step %.4f fwd_ms %.4f' % (d['ms_per_step'], d['forward_ms']), {k:v for k,v in d['stage_ms_per_view'].items() if 'render' in k or 'preprocess' in k or 'sort' in k or 'refl' in k or 'emit' in k or 'scan' in k or 'ranges' in k})
+if 'c5' in d: print('   c5 %.4f' % d['c5']['ms_per_step'], d['c5']['stage_ms_per_step'])
 " >> gpurun_out/ab.txt || echo "FAILED" >> gpurun_out/ab.txt
 done
 cat gpurun_out/ab.txt

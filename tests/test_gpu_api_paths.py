@@ -294,6 +294,33 @@ def test_grad_sink_with_odd_gaussian_count_stays_16_byte_aligned(P):
         HipSurfel(kw, make_sink=bad_sink).backward(g["dL_dcolor"], g["dL_dplanes"], g["dL_drefl"])
 
 
+@pytest.mark.parametrize("variant", ["S", "G"])
+@pytest.mark.parametrize("factor", [2500.0, 6000.0])
+def test_far_scenes_keep_the_depth_order(variant, factor):
+    """Depths of 10^4: the depth pre-sort orders the raw float bits (31 bits, four 8-bit digit places whose histogram is accumulated by
+    gaussian_stats_kernel), so the top digit place is exercised with more than one value — the C1-C5 scenes live in [0.2, 8].  The whole scene
+    scaled about the camera (same image, depths x factor) must give the oracle's point list, keys and ranges."""
+    orc = _orc()
+    kw, _, _ = scene_kwargs(variant, 3000, 192, 128, 55, -2.6, 2, (0.1, 0.1, 0.1))
+    kw["means3D"] = (kw["means3D"] * factor).astype(np.float32)
+    kw["scales"] = (kw["scales"] * factor).astype(np.float32)
+    if variant == "S":
+        o = orc.SurfelOracle(np.float32)
+        ref = o.forward(**kw)
+        hip = HipSurfel(kw)
+    else:
+        o = orc.GaussOracle(np.float32)
+        ref = o.forward(**kw)
+        hip = HipGauss(kw)
+    d = o.state("depths")[o.state("radii") > 0]
+    assert d.max() > 13107.0 and (d < 4096.0).any()        # (several values of the top 8-bit digit: float exponents 2^11 .. 2^14)
+    assert hip.R == ref["num_rendered"] > 0
+    np.testing.assert_array_equal(hip.state("point_list").astype(np.uint32), o.state("point_list"))
+    np.testing.assert_array_equal(hip.state("keys").astype(np.uint64), o.state("keys"))
+    np.testing.assert_array_equal(hip.state("ranges").astype(np.uint32), o.state("ranges"))
+    assert psnr(hip.out()["color"], ref["color"]) >= 50
+
+
 def test_pixels_without_contributors_report_zero_median():
     """A sparse scene: most pixels see no surfel at all.  Their median-contributor entry is the reference's float -1
     converted with saturation, i.e. 0 (the C++ conversion is undefined and once compiled to lane garbage)."""
