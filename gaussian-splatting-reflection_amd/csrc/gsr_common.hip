@@ -162,7 +162,8 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.flags = c.take<int>(4);
 	g.depth_sorted = c.take<uint32_t>(P);
 	g.order = c.take<uint32_t>(P);
-	g.offsets_sorted = c.take<uint32_t>(P);
+	g.emit_state_bytes = ((((P + 255) / 256 + 1) * sizeof(unsigned long long)) + 15) & ~(size_t)15;
+	g.emit_state = c.take<unsigned long long>(g.emit_state_bytes / sizeof(unsigned long long));
 	g.scan_temp = c.take<char>(scan_bytes);
 	g.scan_temp_bytes = scan_bytes;
 	g.depth_sort_temp = g.scan_temp ? static_cast<char*>(g.scan_temp) + scan_part_bytes(P) : nullptr;
@@ -252,29 +253,85 @@ __global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, cons
 static_assert(STATS_BLOCK == DEPTH_KEY_PLACES * 256u, "one histogram bin per thread");
 
 #define EMIT_BIG 8u   // a Gaussian with more instances than this is emitted by its whole wave (C3: 32 -> 0.046 ms, 16 -> 0.045, 8 -> 0.042)
+// State word of the scan inside emit_tiles_kernel: flag in bits 62-63 (0 nothing yet, 1 = this workgroup's own instance count, 2 = inclusive
+// prefix up to and including this workgroup), value in the low 32 bits.  One 64-bit relaxed agent-scope atomic carries flag and value
+// together, so no fence is needed (an agent-scope release fence writes back the XCD's L2 on this part: gsr_sort.hpp).
+__device__ __forceinline__ unsigned long long emit_pack(uint32_t flag, uint32_t v) { return ((unsigned long long)flag << 62) | (unsigned long long)v; }
+__device__ __forceinline__ void emit_publish(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long emit_peek(unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// duplicateWithKeys (rasterizer_impl.cu:70-111) for the Gaussians in depth order.  Round 3: the exclusive prefix sum of the instance
+// counts in that order — where each Gaussian's run starts — is computed HERE, as a single-pass chained scan (per-workgroup scan +
+// decoupled look-back over the workgroups in front, wave-parallel), instead of a rocPRIM inclusive_scan in front of this kernel: that
+// scan read tiles_touched through the depth order (a random 4-byte gather per Gaussian) and cost two dispatches, 19 us at C3 and 97 us
+// at C5; the count is the area of the tile rectangle, which this kernel gathers anyway (culled Gaussians carry an empty rectangle).
 __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
-                                                         const uint32_t* __restrict__ offsets_sorted, const uint32_t* __restrict__ tiles_touched,
+                                                         unsigned long long* __restrict__ scan_state,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
                                                          uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes,
                                                          unsigned long long* __restrict__ blend_mask, size_t blend_words) {
 	const int i = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	__shared__ uint32_t s_wsum[4];
+	__shared__ uint32_t s_base;
+	// the rectangle is one 8-byte gather; its area is the number of instances (tiles_touched)
+	const bool valid = i < P;
+	uint32_t idx = 0u, r0 = 0u, r1 = 0u;
+	if (valid) {
+		idx = order[i];
+		const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
+		r0 = r.x; r1 = r.y;
+	}
+	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
+	const uint32_t cnt = (x1 - x0) * (y1 - y0);
 	// (the forward tile kernel only writes the blend masks of the batches it reaches: the rest must read as "nothing blended")
 	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * 256u) blend_mask[t] = 0ull;
 	// the tile ranges (tile_ranges_kernel fills the non-empty ones after the sort) and the look-back state of the tile-id
 	// sort that follows are cleared here: a dispatch of its own costs ~5 us whatever it does
 	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
 	sort_clear_region(sort_clear, sort_clear_bytes, (size_t)i, (size_t)gridDim.x * 256u);
-	// the instance count comes from the scan (two coalesced reads) and the rectangle is one 8-byte gather
-	const bool valid = i < P;
-	const uint32_t off = (valid && i > 0) ? offsets_sorted[i - 1] : 0u;
-	const uint32_t cnt = valid ? offsets_sorted[i] - off : 0u;
-	uint32_t idx = 0u, r0 = 0u, r1 = 0u;
-	if (cnt != 0u) {
-		idx = order[i];
-		const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
-		r0 = r.x; r1 = r.y;
+	// ---- scan of the counts: inside the wave, across the four waves, across the workgroups in front
+	uint32_t incl = cnt;
+#pragma unroll
+	for (uint32_t o = 1; o < 64; o <<= 1) {
+		const uint32_t v = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += v;
 	}
-	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
+	if (lane == 63u) s_wsum[wave] = incl;
+	__syncthreads();
+	if (wave == 0u) {
+		const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+		const int bid = (int)blockIdx.x;
+		uint32_t prefix = 0u;
+		if (bid == 0) {
+			if (lane == 0u) emit_publish(scan_state, emit_pack(2u, total));
+		} else {
+			if (lane == 0u) emit_publish(scan_state + bid, emit_pack(1u, total));
+			int j = bid - 1;                         // lane l examines workgroup j - l
+			for (;;) {
+				const int tgt = j - (int)lane;
+				const unsigned long long st = tgt >= 0 ? emit_peek(scan_state + tgt) : emit_pack(2u, 0u);   // in front of workgroup 0: prefix 0
+				const uint32_t flag = (uint32_t)(st >> 62);
+				const unsigned long long done = __ballot(flag == 2u), empty = __ballot(flag == 0u);
+				// the nearest workgroup that already knows its inclusive prefix ends the walk; everything nearer must at least have published its count
+				const int stop = done != 0ull ? __ffsll((long long)done) - 1 : 63;
+				const unsigned long long need = stop == 63 ? ~0ull : ((2ull << stop) - 1ull);
+				if ((empty & need) != 0ull) continue;      // somebody nearer has not published yet: look again (workgroups start in id order)
+				uint32_t v = (int)lane <= stop ? (uint32_t)st : 0u;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+				prefix += v;
+				if (done != 0ull) break;
+				j -= 64;
+			}
+			if (lane == 0u) emit_publish(scan_state + bid, emit_pack(2u, prefix + total));
+		}
+		if (lane == 0u) s_base = prefix;
+	}
+	__syncthreads();
+	uint32_t wbase = s_base;
+	for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
+	const uint32_t off = wbase + incl - cnt;
 	// small Gaussians (the mean is 4 instances): one thread writes its own short run
 	if (cnt != 0u && cnt <= EMIT_BIG) {
 		uint32_t o = off;
@@ -288,7 +345,6 @@ __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* 
 	// large ones (a near Gaussian covers up to every tile of the image; one thread looping over thousands of instances
 	// was the whole tail of this kernel) are emitted by all 64 lanes of the wave, 256 contiguous bytes per store
 	unsigned long long big = __ballot(cnt > EMIT_BIG);
-	const uint32_t lane = threadIdx.x & 63u;
 	while (big) {
 		const int src = __ffsll((long long)big) - 1;
 		big &= big - 1;
@@ -428,8 +484,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	GSR_HIP_CHECK(hipEventRecord(readback_done, stream));
 	{
 		// level 1 (independent of num_rendered, so it runs while the host waits for the read-back): depth order of the
-		// Gaussians (31 key bits: depths are positive floats, their bit patterns order like the values) and the scan of
-		// tiles_touched taken in that order
+		// Gaussians (31 key bits: depths are positive floats, their bit patterns order like the values); the scan of the
+		// instance counts taken in that order happens inside emit_tiles_kernel
 		StageTimer st_(GSR_STAGE_SORT, stream);
 		size_t tmp = geom.depth_sort_bytes;
 		if (own_depth_sort)   // look-back state cleared by the preprocess kernel, digit counts accumulated by gaussian_stats_kernel: four dispatches
@@ -439,10 +495,6 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		else
 			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
-		tmp = (size_t)(static_cast<char*>(geom.depth_sort_temp) - static_cast<char*>(geom.scan_temp));
-		auto touched = rocprim::make_transform_iterator((const uint32_t*)geom.order, TouchedInOrder{geom.tiles_touched});
-		GSR_HIP_CHECK(rocprim::inclusive_scan(geom.scan_temp, tmp, touched, geom.offsets_sorted, (size_t)P, rocprim::plus<uint32_t>(), stream,
-		                                      false));
 	}
 	GSR_HIP_CHECK(hipEventSynchronize(readback_done));
 	unsigned long long total64;
@@ -465,7 +517,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
-		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.offsets_sorted, geom.tiles_touched, b.tile_keys_unsorted,
+		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
 		                                                       16 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);

@@ -90,6 +90,7 @@ gauss_preprocess_one(int idx, int D, int M, const float* __restrict__ means, con
 #pragma clang fp contract(off)
 	radii[idx] = 0;
 	g.tiles_touched[idx] = 0;
+	reinterpret_cast<uint2*>(g.rect)[idx] = make_uint2(0u, 0u);   // empty tile rectangle: emit_tiles_kernel takes the instance count from its area
 	g.depths[idx] = __int_as_float(0x7f7fffff);   // culled: sorts behind every visible Gaussian in the depth pre-sort
 	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
 	const float* vm = cam.view;
@@ -183,6 +184,7 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
+	sort_clear_region(g.emit_state, g.emit_state_bytes, (size_t)idx, (size_t)gridDim.x * 256u);   // look-back state of emit_tiles_kernel's scan
 	if (idx == 0) { g.flags[2] = 0; g.flags[3] = 0; }   // num_rendered (64 bits): accumulated by gaussian_stats_kernel
 	__shared__ float4 s_out[4][6 * 65];     // per wave: 4 planes of 65 float4 (record), then 2 (cull record), then 6 planes of 65 dwords (cov3D)
 	const int lane = threadIdx.x & 63;

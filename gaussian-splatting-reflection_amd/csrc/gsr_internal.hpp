@@ -88,7 +88,8 @@ struct GeomState {
 	                         //         gaussian_stats_kernel
 	uint32_t* depth_sorted;  // P        depth bits in ascending order (output of the depth pre-sort; keys only)
 	uint32_t* order;         // P        Gaussian index at each position of the depth order (stable: ties by index)
-	uint32_t* offsets_sorted;// P        inclusive scan of tiles_touched taken in depth order
+	unsigned long long* emit_state;   // one word per 256 Gaussians: decoupled look-back state of emit_tiles_kernel's scan of the instance counts
+	size_t emit_state_bytes;          //   (multiple of 16; zeroed by the preprocess kernel)
 	void* scan_temp;         // temp of the two scans (shared) followed by the temp of the P-sized depth sort
 	size_t scan_temp_bytes;
 	void* depth_sort_temp;   // = scan_temp + scan part; its first depth_sort_clear bytes are zeroed by the preprocess kernel (they start with
