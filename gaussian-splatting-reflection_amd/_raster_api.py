@@ -60,6 +60,7 @@ class Variant:
     grads_of: Callable                                 # _C backward return tuple -> dict tensor name -> gradient
     optional_grads: Tuple[str, ...]                    # inputs whose gradient is None when they were passed as placeholders
     sinkable: Dict[str, str] = field(default_factory=dict)   # apply() tensor name -> gradient-sink key
+    skippable: Dict[str, str] = field(default_factory=dict)  # apply() tensor name -> `unused` key of the _C backward: not computed when the input was a placeholder
     snapshot_on_debug: bool = False
 
 
@@ -109,6 +110,10 @@ def build_api(v: Variant):
                             for i, (g, m) in enumerate(zip(grad_outputs, ctx.out_meta))]
             c_args = v.pack_backward(saved, settings, grad_outputs, ctx.num_rendered, buffers, radii)
             sink_kw = {} if ctx.grad_sink is None else {"grad_sink": ctx.grad_sink.tensors, "accumulate": ctx.grad_sink.accumulate}
+            # gradients of inputs that were passed as empty placeholders are dropped below anyway: tell the kernel not to write them
+            unused = tuple(key for name, key in v.skippable.items() if saved.get(name) is None or saved[name].numel() == 0)
+            if unused:
+                sink_kw["unused"] = unused
             if v.snapshot_on_debug and settings.debug:
                 host_copy = cpu_deep_copy_tuple(c_args)
                 try:

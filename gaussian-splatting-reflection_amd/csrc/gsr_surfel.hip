@@ -1078,11 +1078,13 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 		}
 	}
 	const float m2d[3] = {out_m2x, out_m2y, 0.f};
-	wave_store_rows<3, false>(tile, gcol, dL_dcolor + (size_t)g0 * 3, nrows, lane);
-	wave_store_rows<3, false>(tile, gnrm, dL_dnormal + (size_t)g0 * 3, nrows, lane);
+	// (per-view outputs the caller did not ask for — NULL — are not written: 60 of this kernel's ~690 bytes per surfel when shs and
+	// scales / rotations are the inputs, as in the reference's training path)
+	if (dL_dcolor != nullptr) wave_store_rows<3, false>(tile, gcol, dL_dcolor + (size_t)g0 * 3, nrows, lane);
+	if (dL_dnormal != nullptr) wave_store_rows<3, false>(tile, gnrm, dL_dnormal + (size_t)g0 * 3, nrows, lane);
 	wave_store_rows<3, false>(tile, m2d, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
 	wave_store_rows<3, ACC>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
-	wave_store_rows<9, false>(tile, dTout, dL_dtransMat + (size_t)g0 * 9, nrows, lane);
+	if (dL_dtransMat != nullptr) wave_store_rows<9, false>(tile, dTout, dL_dtransMat + (size_t)g0 * 9, nrows, lane);
 	if (in_range) {
 		put<ACC>(dL_dscale + 2 * idx, dscale[0]); put<ACC>(dL_dscale + 2 * idx + 1, dscale[1]);
 		float4* rq = reinterpret_cast<float4*>(dL_drot) + idx;
@@ -1179,7 +1181,7 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_surfel_backward: invalid size"); return GSR_E_INVALID; }
 	if (P == 0) return 0;
 	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer) || !dL_dpix || !dL_dothers || !dL_drefl_strength_map || !dL_dmean2D ||
-	    !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_drefl_strengths || !dL_dmean3D || !dL_dtransMat || !dL_dscale || !dL_drot ||
+	    !dL_dopacity || !dL_drefl_strengths || !dL_dmean3D || !dL_dscale || !dL_drot || (!shs && !dL_dcolor) || (!scales && !dL_dtransMat) ||
 	    (shs && !dL_dsh) || !radii || !means3D) {
 		set_error("gsr_surfel_backward: missing required pointer");
 		return GSR_E_INVALID;

@@ -66,13 +66,15 @@ def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_streng
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, dL_dout_refl_strength_map, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, grad_sink=None, accumulate=False):
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, grad_sink=None, accumulate=False, unused=()):
     """Same positional arguments and return tuple as the reference's `_C.rasterize_gaussians_backward`.  Keyword-only
     extension: `grad_sink` maps any of means3D (P,3), shs (P,M,3), opacities (P,1), scales (P,2), rotations (P,4),
     refl_strengths (P,1) to a preallocated contiguous float32 tensor (e.g. views of one flat all-reduce / optimizer buffer,
     gsr_dist.FlatGrads); the per-Gaussian backward kernel then writes — or, with accumulate=True, ADDS — those gradients
     straight into them and the corresponding entries of the return tuple are those same tensors.  The sink belongs to
-    this call: there is no module-level state."""
+    this call: there is no module-level state.  `unused` (keyword-only extension, what the autograd wrapper passes): any of "colors",
+    "transMat" — gradients of inputs the caller did not supply (shs instead of colors_precomp, scales / rotations instead of
+    transMat_precomp); the kernel does not write them and the tuple holds empty tensors in their place."""
     M = sh.size(1) if sh.numel() != 0 else 0
     if grad_sink:
         unknown = set(grad_sink) - SINKABLE
@@ -81,7 +83,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     if accumulate and (not grad_sink or not set(grad_sink) >= (SINKABLE - ({"shs"} if M == 0 else set()))):
         # the kernel has ONE accumulate switch for all six parameter gradients: fresh (uninitialised) tensors cannot be added to
         raise ValueError("accumulate=True needs a sink for every parameter gradient: " + ", ".join(sorted(SINKABLE)))
-    if _gsr.PYBIND is not None and not grad_sink:
+    unused = frozenset(unused)
+    if unused - {"colors", "transMat"} or ("colors" in unused and sh.numel() == 0) or ("transMat" in unused and scales.numel() == 0):
+        raise ValueError("unused: 'colors' needs shs as the colour input, 'transMat' needs scales / rotations; got %r" % (sorted(unused),))
+    if _gsr.PYBIND is not None and not grad_sink and not unused:
         return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
             background, means3D, radii, colors, refl_strengths, scales, rotations, float(scale_modifier), transMat_precomp, viewmatrix, projmatrix,
             float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_others,
@@ -112,8 +117,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
                                  "to multiples of 4 floats as gsr_dist.FlatGrads does")
             return t
         return mk0(shape, **kw)
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dnormal = mk((P, 3), "means3D", **o), mk((P, 3), **o), mk((P, NUM_CHANNELS), **o), mk((P, 3), **o)
-    dL_dopacity, dL_dtransMat, dL_dsh = mk((P, 1), "opacities", **o), mk((P, 9), **o), mk((P, M, 3), "shs", **o)
+    # dL_dnormal3D is internal to the reference's backward (never returned): not materialised at all
+    dL_dmeans3D, dL_dmeans2D, dL_dnormal = mk((P, 3), "means3D", **o), mk((P, 3), **o), None
+    dL_dcolors = torch.empty(0, **o) if "colors" in unused else mk((P, NUM_CHANNELS), **o)
+    dL_dtransMat = torch.empty(0, **o) if "transMat" in unused else mk((P, 9), **o)
+    dL_dopacity, dL_dsh = mk((P, 1), "opacities", **o), mk((P, M, 3), "shs", **o)
     dL_dscales, dL_drotations, dL_drefl = mk((P, 2), "scales", **o), mk((P, 4), "rotations", **o), mk((P, 1), "refl_strengths", **o)
     if dL_dout_refl_strength_map is None or dL_dout_refl_strength_map.numel() == 0:
         dL_dout_refl_strength_map = torch.zeros((1, H, W), **o)

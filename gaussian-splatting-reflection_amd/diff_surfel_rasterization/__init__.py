@@ -58,6 +58,7 @@ _VARIANT = Variant(
     optional_grads=("sh", "colors_precomp", "refl_strengths", "scales", "rotations", "cov3Ds_precomp", "env_scope_mask"),
     sinkable={"means3D": "means3D", "sh": "shs", "opacities": "opacities", "scales": "scales", "rotations": "rotations",
               "refl_strengths": "refl_strengths"},
+    skippable={"colors_precomp": "colors", "cov3Ds_precomp": "transMat"},
     snapshot_on_debug=True)
 
 GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)

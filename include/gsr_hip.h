@@ -73,7 +73,10 @@ int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M
  *   dL_dpix float[3,H,W]; dL_dothers float[8,H,W] (planes 0-6 read); dL_drefl_strength_map float[H,W]
  *   Outputs (fully written, no pre-zeroing needed): dL_dmean2D[P,3] dL_dnormal[P,3] dL_dopacity[P]
  *   dL_dcolor[P,3] dL_drefl_strengths[P] dL_dmean3D[P,3] dL_dtransMat[P,9] dL_dsh[P,M,3]
- *   dL_dscale[P,2] dL_drot[P,4]. */
+ *   dL_dscale[P,2] dL_drot[P,4].
+ *   Extension: dL_dnormal may be NULL, dL_dcolor may be NULL when shs is given, dL_dtransMat may be NULL when scales / rotations
+ *   are given: those per-view gradients then belong to inputs the caller did not supply and are not written (the reference fills
+ *   zero-initialised tensors for them, rasterize_points.cu:207-226, which its autograd wrapper then drops). */
 int gsr_surfel_backward(int P, int D, int M, int R, const float* background, int width, int height,
                         const float* means3D, const float* shs, const float* colors_precomp,
                         const float* refl_strengths, const float* scales, float scale_modifier, const float* rotations,
