@@ -546,13 +546,15 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 	if (in_range) {
 		dL_drefl[idx] = a1.z;
 		if (has_invdepth) dL_dinvdepth[idx] = a1.w;
-		reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
+		if (dL_dconic != nullptr) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
 	}
 	{
 		const float c3[3] = {a0.x, a0.y, a0.z}, n3[3] = {a0.w, a1.x, a1.y}, m3[3] = {a2.x, a2.y, 0.f}, p3[3] = {a2.z, a2.w, 0.f};
-		wave_store_rows<3, false>(tile, c3, dL_dcolor + (size_t)g0 * 3, nrows, lane);
+		// (outputs the caller did not ask for — NULL — are not written: the tile kernel's intermediate dL_dmean2D / dL_dconic, which the
+		// reference's binding never returns, and the gradients of inputs that were not supplied)
+		if (dL_dcolor != nullptr) wave_store_rows<3, false>(tile, c3, dL_dcolor + (size_t)g0 * 3, nrows, lane);
 		wave_store_rows<3, false>(tile, n3, dL_dnormals + (size_t)g0 * 3, nrows, lane);
-		wave_store_rows<3, false>(tile, m3, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
+		if (dL_dmean2D != nullptr) wave_store_rows<3, false>(tile, m3, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
 		wave_store_rows<3, false>(tile, p3, dL_dmean2D_pixels + (size_t)g0 * 3, nrows, lane);
 	}
 	float dL_dopac = a3.w;
@@ -717,7 +719,7 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 		}
 	}
 	wave_store_rows<3, false>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
-	wave_store_rows<6, false>(tile, dcov, dL_dcov3D + (size_t)g0 * 6, nrows, lane);
+	if (dL_dcov3D != nullptr) wave_store_rows<6, false>(tile, dcov, dL_dcov3D + (size_t)g0 * 6, nrows, lane);
 	wave_store_rows<3, false>(tile, dscale, dL_dscale + (size_t)g0 * 3, nrows, lane);
 	if (in_range) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
 }
@@ -814,8 +816,8 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 	hipStream_t stream = (hipStream_t)stream_;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_gauss_backward: invalid size"); return GSR_E_INVALID; }
 	if (P == 0) return 0;
-	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer) || !dL_dpix || !dL_dnormal_map || !dL_drefl_strength_map || !dL_dmean2D ||
-	    !dL_dmean2D_pixels || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dnormals || !dL_drefl_strengths || !dL_dmean3D || !dL_dcov3D ||
+	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer) || !dL_dpix || !dL_dnormal_map || !dL_drefl_strength_map ||
+	    !dL_dmean2D_pixels || !dL_dopacity || (!shs && !dL_dcolor) || !dL_dnormals || !dL_drefl_strengths || !dL_dmean3D || (!scales && !dL_dcov3D) ||
 	    !dL_dscale || !dL_drot || (shs && !dL_dsh) || (dL_invdepths && !dL_dinvdepth) || !radii || !means3D || !opacities) {
 		set_error("gsr_gauss_backward: missing required pointer");
 		return GSR_E_INVALID;

@@ -96,14 +96,19 @@ SurfelBackward(const torch::Tensor& background, const torch::Tensor& means3D, co
                const torch::Tensor& transMat_precomp, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
                const float tan_fovy, const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_others,
                const torch::Tensor& dL_dout_refl_strength_map, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
-               const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug) {
+               const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug,
+               const int unused) {
+	// unused (extension; 0 = the reference's behaviour): bit 0 = dL_dcolors, bit 1 = dL_dtransMat belong to inputs the caller did not supply
+	// and are neither computed nor allocated (empty tensors in the tuple).  dL_dnormal3D is internal to the reference's backward: never allocated.
 	const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
 	const int M = sh.numel() ? (int)sh.size(1) : 0;
 	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto mk = [&](std::vector<int64_t> shape) { return P ? torch::empty(shape, f) : torch::zeros(shape, f); };   // the library writes every element
-	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D = mk({P, 3}), dL_dcolors = mk({P, 3}), dL_dnormal = mk({P, 3}), dL_dopacity = mk({P, 1}),
-	     dL_dtransMat = mk({P, 9}), dL_dsh = mk({P, M, 3}), dL_dscales = mk({P, 2}), dL_drotations = mk({P, 4}), dL_drefl = mk({P, 1});
+	const bool no_col = (unused & 1) && sh.numel() != 0, no_tm = (unused & 2) && scales.numel() != 0;
+	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D = mk({P, 3}), dL_dcolors = no_col ? torch::empty({0}, f) : mk({P, 3}), dL_dopacity = mk({P, 1}),
+	     dL_dtransMat = no_tm ? torch::empty({0}, f) : mk({P, 9}), dL_dsh = mk({P, M, 3}), dL_dscales = mk({P, 2}), dL_drotations = mk({P, 4}),
+	     dL_drefl = mk({P, 1});
 	if (P != 0) {
 		torch::Tensor grefl_t = dL_dout_refl_strength_map.numel() ? dL_dout_refl_strength_map : torch::zeros({1, H, W}, f);
 		FloatArg bg(background, "background"), m3(means3D, "means3D"), shc(sh, "sh"), col(colors, "colors"), refl(refl_strengths, "refl_strengths"),
@@ -113,9 +118,10 @@ SurfelBackward(const torch::Tensor& background, const torch::Tensor& means3D, co
 		auto rad = radii.contiguous();
 		check(gsr_surfel_backward(P, degree, M, R, bg.p, W, H, m3.p, shc.p, col.p, refl.p, sca.p, scale_modifier, rot.p, tm.p, vm.p, pm.p, cp.p, tan_fovx,
 		                          tan_fovy, rad.data_ptr<int>(), geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
-		                          imageBuffer.data_ptr(), gcol.p, goth.p, grefl.p, dL_dmeans2D.data_ptr<float>(), dL_dnormal.data_ptr<float>(),
-		                          dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(), dL_drefl.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
-		                          dL_dtransMat.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
+		                          imageBuffer.data_ptr(), gcol.p, goth.p, grefl.p, dL_dmeans2D.data_ptr<float>(), nullptr,
+		                          dL_dopacity.data_ptr<float>(), no_col ? nullptr : dL_dcolors.data_ptr<float>(), dL_drefl.data_ptr<float>(),
+		                          dL_dmeans3D.data_ptr<float>(), no_tm ? nullptr : dL_dtransMat.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
+		                          dL_dscales.data_ptr<float>(),
 		                          dL_drotations.data_ptr<float>(), debug, current_stream(means3D)),
 		      "gsr_surfel_backward");
 	}
@@ -156,14 +162,17 @@ GaussBackward(const torch::Tensor& background, const torch::Tensor& means3D, con
               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy, const torch::Tensor& dL_dout_color,
               const torch::Tensor& dL_dout_invdepth, const torch::Tensor& dL_dout_normal_map, const torch::Tensor& dL_dout_refl_strength_map,
               const torch::Tensor& sh, const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
-              const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool antialiasing, const bool debug) {
+              const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool antialiasing, const bool debug, const int unused) {
+	// unused: bit 0 = dL_dcolors, bit 1 = dL_dcov3D (see SurfelBackward).  dL_dmean2D / dL_dconic are intermediates the reference's binding
+	// never returns (DGR rasterize_points.cu:263): not allocated.
 	const int P = (int)means3D.size(0), H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
 	const int M = sh.numel() ? (int)sh.size(1) : 0;
 	const DeviceGuard guard(means3D.device());
 	auto f = means3D.options().dtype(torch::kFloat32);
 	auto mk = [&](std::vector<int64_t> shape) { return P ? torch::empty(shape, f) : torch::zeros(shape, f); };
-	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D = mk({P, 3}), dL_dmeans2D_pixels = mk({P, 3}), dL_dcolors = mk({P, 3}), dL_dnormals = mk({P, 3}),
-	     dL_dconic = mk({P, 2, 2}), dL_dopacity = mk({P, 1}), dL_dcov3D = mk({P, 6}), dL_dsh = mk({P, M, 3}), dL_dscales = mk({P, 3}),
+	const bool no_col = (unused & 1) && sh.numel() != 0, no_cov = (unused & 2) && scales.numel() != 0;
+	auto dL_dmeans3D = mk({P, 3}), dL_dmeans2D_pixels = mk({P, 3}), dL_dcolors = no_col ? torch::empty({0}, f) : mk({P, 3}), dL_dnormals = mk({P, 3}),
+	     dL_dopacity = mk({P, 1}), dL_dcov3D = no_cov ? torch::empty({0}, f) : mk({P, 6}), dL_dsh = mk({P, M, 3}), dL_dscales = mk({P, 3}),
 	     dL_drotations = mk({P, 4}), dL_drefl = mk({P, 1});
 	// depth / refl-strength backward are active whenever the incoming grad tensors are non-empty (DGR rasterize_points.cu:196-216)
 	const bool has_inv = dL_dout_invdepth.numel() != 0, has_refl = dL_dout_refl_strength_map.numel() != 0;
@@ -178,10 +187,10 @@ GaussBackward(const torch::Tensor& background, const torch::Tensor& means3D, con
 		auto rad = radii.contiguous();
 		check(gsr_gauss_backward(P, degree, M, R, bg.p, W, H, m3.p, shc.p, col.p, nrm.p, refl.p, opa.p, sca.p, scale_modifier, rot.p, cov.p, vm.p, pm.p, cp.p,
 		                         tan_fovx, tan_fovy, rad.data_ptr<int>(), geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
-		                         imageBuffer.data_ptr(), gcol.p, gnrm.p, grefl.p, has_inv ? ginv.p : nullptr, dL_dmeans2D.data_ptr<float>(),
-		                         dL_dmeans2D_pixels.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
+		                         imageBuffer.data_ptr(), gcol.p, gnrm.p, grefl.p, has_inv ? ginv.p : nullptr, nullptr,
+		                         dL_dmeans2D_pixels.data_ptr<float>(), nullptr, dL_dopacity.data_ptr<float>(), no_col ? nullptr : dL_dcolors.data_ptr<float>(),
 		                         dL_dnormals.data_ptr<float>(), dL_drefl.data_ptr<float>(), has_inv ? dL_dinvdepths.data_ptr<float>() : nullptr,
-		                         dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
+		                         dL_dmeans3D.data_ptr<float>(), no_cov ? nullptr : dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr,
 		                         dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), antialiasing, debug, current_stream(means3D)),
 		      "gsr_gauss_backward");
 	}
@@ -202,7 +211,7 @@ torch::Tensor MarkVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 	m.def("surfel_rasterize_gaussians", &SurfelForward);
-	m.def("surfel_rasterize_gaussians_backward", &SurfelBackward);
+	m.def("surfel_rasterize_gaussians_backward", &SurfelBackward);      // (last argument: `unused` bit mask, 0 = the reference's behaviour)
 	m.def("gauss_rasterize_gaussians", &GaussForward);
 	m.def("gauss_rasterize_gaussians_backward", &GaussBackward);
 	m.def("mark_visible", &MarkVisible);

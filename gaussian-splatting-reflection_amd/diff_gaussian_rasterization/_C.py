@@ -63,24 +63,33 @@ def rasterize_gaussians(background, means3D, colors, normals, refl_strengths, op
 def rasterize_gaussians_backward(background, means3D, radii, colors, normals, refl_strengths, opacities, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_invdepth,
                                  dL_dout_normal_map, dL_dout_refl_strength_map, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 antialiasing, debug, *, grad_sink=None, accumulate=False):
+                                 antialiasing, debug, *, grad_sink=None, accumulate=False, unused=()):
+    """`unused` (keyword-only extension, what the autograd wrapper passes): any of "colors", "cov3D" — gradients of inputs the caller did not
+    supply (shs instead of colors_precomp, scales / rotations instead of cov3D_precomp): not computed, empty tensors in the tuple."""
     if grad_sink or accumulate:
         raise NotImplementedError("gradient sinks are provided for the surfel rasterizer (the one the training path calls) only")
+    unused = frozenset(unused)
+    if unused - {"colors", "cov3D"} or ("colors" in unused and sh.numel() == 0) or ("cov3D" in unused and scales.numel() == 0):
+        raise ValueError("unused: 'colors' needs shs as the colour input, 'cov3D' needs scales / rotations; got %r" % (sorted(unused),))
     if _gsr.PYBIND is not None:
         e = lambda t: t if t is not None else torch.empty(0, device=means3D.device)
         return _gsr.PYBIND.gauss_rasterize_gaussians_backward(
             background, means3D, radii, colors, normals, refl_strengths, opacities, scales, rotations, float(scale_modifier), cov3D_precomp,
             viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color, e(dL_dout_invdepth), dL_dout_normal_map,
-            e(dL_dout_refl_strength_map), sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(antialiasing), bool(debug))
+            e(dL_dout_refl_strength_map), sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, bool(antialiasing), bool(debug),
+            (1 if "colors" in unused else 0) | (2 if "cov3D" in unused else 0))
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
     dev = means3D.device
     o = dict(dtype=torch.float32, device=dev)
     mk = torch.empty if P != 0 else torch.zeros
-    dL_dmeans3D, dL_dmeans2D, dL_dmeans2D_pixels = mk((P, 3), **o), mk((P, 3), **o), mk((P, 3), **o)
-    dL_dcolors, dL_dnormals, dL_dconic = mk((P, NUM_CHANNELS), **o), mk((P, 3), **o), mk((P, 2, 2), **o)
-    dL_dopacity, dL_dcov3D, dL_dsh = mk((P, 1), **o), mk((P, 6), **o), mk((P, M, 3), **o)
+    # dL_dmean2D (the one that feeds the 3-D gradient) and dL_dconic are intermediates of the reference's backward, never returned: not materialised
+    dL_dmeans3D, dL_dmeans2D, dL_dmeans2D_pixels = mk((P, 3), **o), None, mk((P, 3), **o)
+    dL_dcolors = torch.empty(0, **o) if "colors" in unused else mk((P, NUM_CHANNELS), **o)
+    dL_dnormals, dL_dconic = mk((P, 3), **o), None
+    dL_dopacity, dL_dsh = mk((P, 1), **o), mk((P, M, 3), **o)
+    dL_dcov3D = torch.empty(0, **o) if "cov3D" in unused else mk((P, 6), **o)
     dL_dscales, dL_drotations = mk((P, 3), **o), mk((P, 4), **o)
     # depth / refl-strength backward are active whenever the incoming grad tensors are non-empty
     # (DGR rasterize_points.cu:196-216)

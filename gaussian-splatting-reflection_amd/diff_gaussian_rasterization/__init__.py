@@ -52,6 +52,7 @@ _VARIANT = Variant(
     placeholder=_placeholder, pack_forward=_pack_forward, split_forward=_split_forward, nondiff_outputs=(1,),
     saved=("colors_precomp", "normals", "refl_strengths", "means3D", "scales", "rotations", "cov3Ds_precomp", "sh", "opacities"),
     pack_backward=_pack_backward, grads_of=_grads_of,
-    optional_grads=("sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp"))
+    optional_grads=("sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp"),
+    skippable={"colors_precomp": "colors", "cov3Ds_precomp": "cov3D"})
 
 GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)

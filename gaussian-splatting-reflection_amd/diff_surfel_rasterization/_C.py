@@ -86,12 +86,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     unused = frozenset(unused)
     if unused - {"colors", "transMat"} or ("colors" in unused and sh.numel() == 0) or ("transMat" in unused and scales.numel() == 0):
         raise ValueError("unused: 'colors' needs shs as the colour input, 'transMat' needs scales / rotations; got %r" % (sorted(unused),))
-    if _gsr.PYBIND is not None and not grad_sink and not unused:
+    if _gsr.PYBIND is not None and not grad_sink:
         return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
             background, means3D, radii, colors, refl_strengths, scales, rotations, float(scale_modifier), transMat_precomp, viewmatrix, projmatrix,
             float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_others,
             dL_dout_refl_strength_map if dL_dout_refl_strength_map is not None else torch.empty(0, device=means3D.device), sh, int(degree), campos,
-            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug))
+            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug), (1 if "colors" in unused else 0) | (2 if "transMat" in unused else 0))
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors), ("scales", scales),
                     ("rotations", rotations), ("transMat_precomp", transMat_precomp), ("viewmatrix", viewmatrix),
                     ("projmatrix", projmatrix), ("sh", sh), ("campos", campos), ("binningBuffer", binningBuffer),

@@ -118,7 +118,8 @@ int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M,
 /* Replaces CudaRasterizer::Rasterizer::backward (DGR rasterizer.h:59-101, rasterizer_impl.cu:353-472).
  *   dL_invdepths may be NULL (then dL_dinvdepth is not touched).  dL_dmean2D_pixels is what the
  *   reference hands to Python as grad_means2D (DGR rasterize_points.cu:263).  dL_dconic is float[P,4]
- *   (slots x,y,w used).  Outputs are fully written. */
+ *   (slots x,y,w used).  Outputs are fully written.  *   Extension: dL_dmean2D and dL_dconic (intermediates of the reference's backward that its binding never returns) may be NULL, dL_dcolor
+ *   may be NULL when shs is given and dL_dcov3D when scales / rotations are given: not written then. */
 int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* normals,
                        const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
