@@ -162,7 +162,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.flags = c.take<int>(4);
 	g.depth_sorted = c.take<uint32_t>(P);
 	g.order = c.take<uint32_t>(P);
-	g.emit_state_bytes = ((((P + 255) / 256 + 1) * sizeof(unsigned long long)) + 15) & ~(size_t)15;
+	g.emit_state_bytes = ((((P + 255) / 256 + 1) * sizeof(unsigned long long)) + 15) & ~(size_t)15;   // (enough for any EMIT_BLOCK >= 256)
 	g.emit_state = c.take<unsigned long long>(g.emit_state_bytes / sizeof(unsigned long long));
 	g.scan_temp = c.take<char>(scan_bytes);
 	g.scan_temp_bytes = scan_bytes;
@@ -234,7 +234,16 @@ __global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, cons
 			atomicAdd(&s_hist[key & 255u], 1u);
 			atomicAdd(&s_hist[256u + ((key >> 8) & 255u)], 1u);
 			atomicAdd(&s_hist[512u + ((key >> 16) & 255u)], 1u);
-			atomicAdd(&s_hist[768u + ((key >> 24) & 127u)], 1u);      // (bit 31 is outside the sorted range)
+			// top digit (bit 31 is outside the sorted range): the sign-less exponent's high bits — nearly the same value in every lane, and LDS
+			// atomics to one address serialise: one add per DISTINCT value of the wave instead
+			const uint32_t top = (key >> 24) & 127u;
+			unsigned long long todo = __ballot(1);
+			while (todo != 0ull) {
+				const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)top, __ffsll((long long)todo) - 1);
+				const unsigned long long same = __ballot(top == d0) & todo;
+				if ((t & 63u) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&s_hist[768u + d0], (uint32_t)__popcll(same));
+				todo &= ~same;
+			}
 		}
 	}
 #pragma unroll
@@ -252,6 +261,9 @@ __global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, cons
 }
 static_assert(STATS_BLOCK == DEPTH_KEY_PLACES * 256u, "one histogram bin per thread");
 
+#ifndef EMIT_BLOCK
+#define EMIT_BLOCK 1024    // fewer, larger workgroups shorten the look-back chains of the scan (emit at C3 / C5: 256 -> 0.052 / 0.205 ms, 512 -> 0.048 / 0.179, 1024 -> 0.046 / 0.169)
+#endif
 #define EMIT_BIG 8u   // a Gaussian with more instances than this is emitted by its whole wave (C3: 32 -> 0.046 ms, 16 -> 0.045, 8 -> 0.042)
 // State word of the scan inside emit_tiles_kernel: flag in bits 62-63 (0 nothing yet, 1 = this workgroup's own instance count, 2 = inclusive
 // prefix up to and including this workgroup), value in the low 32 bits.  One 64-bit relaxed agent-scope atomic carries flag and value
@@ -265,14 +277,14 @@ __device__ __forceinline__ unsigned long long emit_peek(unsigned long long* p) {
 // decoupled look-back over the workgroups in front, wave-parallel), instead of a rocPRIM inclusive_scan in front of this kernel: that
 // scan read tiles_touched through the depth order (a random 4-byte gather per Gaussian) and cost two dispatches, 19 us at C3 and 97 us
 // at C5; the count is the area of the tile rectangle, which this kernel gathers anyway (culled Gaussians carry an empty rectangle).
-__global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
+__global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          unsigned long long* __restrict__ scan_state,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
                                                          uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes,
                                                          unsigned long long* __restrict__ blend_mask, size_t blend_words) {
-	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	__shared__ uint32_t s_wsum[4];
+	__shared__ uint32_t s_wsum[EMIT_BLOCK / 64];
 	__shared__ uint32_t s_base;
 	// the rectangle is one 8-byte gather; its area is the number of instances (tiles_touched)
 	const bool valid = i < P;
@@ -285,11 +297,11 @@ __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* 
 	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
 	const uint32_t cnt = (x1 - x0) * (y1 - y0);
 	// (the forward tile kernel only writes the blend masks of the batches it reaches: the rest must read as "nothing blended")
-	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * 256u) blend_mask[t] = 0ull;
+	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * EMIT_BLOCK) blend_mask[t] = 0ull;
 	// the tile ranges (tile_ranges_kernel fills the non-empty ones after the sort) and the look-back state of the tile-id
 	// sort that follows are cleared here: a dispatch of its own costs ~5 us whatever it does
-	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * 256u) ranges[t] = make_uint2(0u, 0u);
-	sort_clear_region(sort_clear, sort_clear_bytes, (size_t)i, (size_t)gridDim.x * 256u);
+	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * EMIT_BLOCK) ranges[t] = make_uint2(0u, 0u);
+	sort_clear_region(sort_clear, sort_clear_bytes, (size_t)i, (size_t)gridDim.x * EMIT_BLOCK);
 	// ---- scan of the counts: inside the wave, across the four waves, across the workgroups in front
 	uint32_t incl = cnt;
 #pragma unroll
@@ -300,7 +312,8 @@ __global__ void __launch_bounds__(256) emit_tiles_kernel(int P, const uint32_t* 
 	if (lane == 63u) s_wsum[wave] = incl;
 	__syncthreads();
 	if (wave == 0u) {
-		const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+		uint32_t total = 0u;
+		for (uint32_t w = 0; w < EMIT_BLOCK / 64; w++) total += s_wsum[w];
 		const int bid = (int)blockIdx.x;
 		uint32_t prefix = 0u;
 		if (bid == 0) {
@@ -517,7 +530,7 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
-		emit_tiles_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, b.tile_keys_unsorted,
+		emit_tiles_kernel<<<(P + EMIT_BLOCK - 1) / EMIT_BLOCK, EMIT_BLOCK, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
 		                                                       16 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
