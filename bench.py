@@ -369,8 +369,12 @@ def main():
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
             "instrumented": "step_ms and stage_ms_per_view come from a second pass of the same K steps with one event per step and the library's "
                             "per-stage hipEvent timers on (each event record costs a 5-10 us bubble between kernels); value / ms_per_step are the "
-                            "uninstrumented pass",
+                            "uninstrumented pass.  refl_bwd is the pixel kernel of the reflection backward; refl_bwd_tail (sort + run combine + unpack) is "
+                            "timed on the stream it runs on: with the asynchronous tail that is the library's side stream, where it runs BESIDE the tile "
+                            "backward and its events span that kernel too (0.8 ms for 0.13 ms of work) - it is not on the step's critical path",
             "step_algorithmic_GBps": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+            "step_frac_of_hbm_peak": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_frac_of_measured_ceiling": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_MEASURED_GBS, 4),
             "roofline": roof,
         }
         out["ranks"] = {"world_size": ranks, "backend": backend or "none", "ms_per_step_per_rank": rank_ms}
