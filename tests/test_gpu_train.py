@@ -33,6 +33,41 @@ def test_photometric_loss_matches_golden_and_oracle(tag):
     assert abs(ssim(img.detach().unsqueeze(0), gt.unsqueeze(0)).item() - float(G[f"{tag}_ssim"])) < 1e-5
 
 
+def test_l1_loss_and_ssim_on_the_same_tensors_share_one_fused_pass():
+    """train.py:167-173 calls l1_loss(image, gt) and ssim(image, gt) one after the other: the second call reuses the first call's pair of sums
+    (one forward kernel, one backward kernel), the loss and its gradient equal photometric_loss's; a changed image or other tensors do not hit."""
+    import _gsr
+    from utils.loss_utils import l1_loss, photometric_loss, ssim
+    g = torch.Generator().manual_seed(21)
+    gt = torch.rand(3, 97, 131, generator=g).cuda()
+    base = torch.rand(3, 97, 131, generator=g).cuda()
+
+    def run(fused):
+        img = base.clone().requires_grad_(True)
+        _gsr.profile_enable(True)
+        if fused:
+            loss = photometric_loss(img, gt, 0.2)
+        else:
+            loss = 0.8 * l1_loss(img, gt) + 0.2 * (1.0 - ssim(img, gt))
+        loss.backward()
+        torch.cuda.synchronize()
+        st = _gsr.profile_collect()
+        _gsr.profile_enable(False)
+        return float(loss), img.grad.clone(), st["loss_fwd"][1], st["loss_bwd"][1]
+    lf, gf, nf_f, nb_f = run(True)
+    lp, gp, nf_p, nb_p = run(False)
+    assert (nf_f, nb_f) == (1, 1) and (nf_p, nb_p) == (1, 1)
+    assert abs(lf - lp) < 1e-6 and (gf - gp).abs().max().item() <= 1e-6 * gf.abs().max().item()
+    # no stale hit: another image object, and the same object modified in place, are recomputed
+    a = base.clone()
+    v1 = float(l1_loss(a, gt))
+    a.mul_(0.5)
+    v2 = float(l1_loss(a, gt))
+    assert abs(v1 - v2) > 1e-3 and abs(v2 - float((a - gt).abs().mean())) < 1e-5
+    with torch.no_grad():
+        assert abs(float(ssim(a, gt)) - float(ssim(a.clone(), gt))) < 1e-7
+
+
 def test_ssim_map_and_ragged_sizes_against_oracle():
     from utils.loss_utils import C1, C2, FusedSSIMMap, photometric_loss
     orc = _orc()
