@@ -512,6 +512,8 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		if (hit) {
 			r = s_wmax[kown];
 			const float m = fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w));
+			// (measured, round 3: leaving the atomic out altogether gains 0.015 ms of 0.50; reading the running maximum first and skipping
+			// attempts that cannot raise it is slower, 0.58 ms)
 			if (m > 0.f) atomicMax(reinterpret_cast<int*>(gaussian_weights) + id, __float_as_int(m));
 		}
 		const lmask forced = __ballot(hit && ((force >> kown) & 1ull) != 0ull);
