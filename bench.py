@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary end-to-end (loss + Adam) timing")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 (5e6 Gaussians, variant G) object")
+    ap.add_argument("--no-c4", action="store_true", help="N = 1: skip the C4-on-one-GPU object (the 8-view batch)")
     ap.add_argument("--sync-reflection-tail", action="store_true",
                     help="keep the cubemap-gradient tail of the reflection backward on the main stream (default: side stream, joined by the all-reduce)")
     ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
@@ -206,9 +207,9 @@ def main():
     # FlatGrads.all_reduce() makes the step's stream wait for it, so it is inside the timed region.
     ar_marks = []      # (start, end) event pairs around the all-reduce; filled only in the instrumented pass
 
-    def step_into(buf, reduce, timed=False):
+    def step_into(buf, reduce, timed=False, batch=None):
         sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
-        for i, view in enumerate(views):
+        for i, view in enumerate(views if batch is None else batch):
             view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
             means2D.grad = None
             final, allmap = render(view, rsink, i > 0)
@@ -309,6 +310,26 @@ def main():
         torch.cuda.synchronize()
         fwd_step_ms = [fmarks[i].elapsed_time(fmarks[i + 1]) for i in range(nf)]
 
+    # BASELINE C4 on this one GPU (reported, never `value`): the batch of 8 views of the same scene per step — first view overwriting the flat
+    # gradient buffer, seven adding to it on the device — as the N > 1 runs shard it over the ranks
+    c4 = None
+    if world == 1 and views_total == 1 and not args.no_c4:
+        batch = views + [View(S, v, W, H, dev) for v in range(1, 8)]
+        for _ in range(2):
+            step_into(scene.grads, lambda b: b.all_reduce(), batch=batch)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        nb = max(3, args.steps // 4)
+        for _ in range(nb):
+            step_into(scene.grads, lambda b: b.all_reduce(), batch=batch)
+        torch.cuda.synchronize()
+        c4_ms = (time.perf_counter() - tc) / nb * 1e3
+        c4 = {"workload": "C4 on one GPU: a batch of 8 views (yaw 0..21 degrees) of the C3 scene per step, gradients accumulated on the device in the flat buffer",
+              "ms_per_step": round(c4_ms, 4), "ms_per_view": round(c4_ms / 8, 4), "views_per_s": round(8e3 / c4_ms, 2), "steps": nb}
+        for view in batch[1:]:
+            view.rasterizer.set_grad_sink(None)
+        del batch
+
     scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
     full = None if args.no_full_step else full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, world, views_total)
 
@@ -386,6 +407,8 @@ def main():
                                 "what": "value / ms_per_step: all-reduce inside every step (what a training step pays); the overlapped figure "
                                         "hides it behind the next step's rendering and is not achievable with an optimizer in the loop",
                                 "xgmi_model_ms": xgmi_model_ms(scene_payload_mb, world)}
+        if c4 is not None:
+            out["c4_one_gpu"] = c4
         if full is not None:
             out["full_train_step"] = full
         if not args.no_c5 and world == 1:

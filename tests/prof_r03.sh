@@ -7,11 +7,11 @@ TAG=${1:-a}
 D=gpurun_out/prof_r03_$TAG
 mkdir -p $R/$D
 cd $R
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step --no-c5 --no-dropin"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-full-step --no-c5 --no-c4 --no-dropin"
 python3 bench.py --steps 50 --warmup 10 > $D/bench.json 2> $D/bench.err && tail -c 400 $D/bench.json || exit 1
 timeout -k 10 300 python3 bench.py --gpus 1 --views 8 --steps 10 --warmup 3 --no-cpu-baseline --no-c5 --no-dropin > $D/bench_views8.json 2> $D/bench_views8.err || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $D/kt -o kt --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c5 --no-dropin > $D/kt.log 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $D/kt_sync -o kt --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c5 --no-dropin --no-full-step --sync-reflection-tail > $D/kt_sync.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $D/kt -o kt --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c5 --no-c4 --no-dropin > $D/kt.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $D/kt_sync -o kt --output-format csv -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c5 --no-c4 --no-dropin --no-full-step --sync-reflection-tail > $D/kt_sync.log 2>&1 || exit 1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES"; do
   i=$((i+1))
