@@ -86,6 +86,9 @@ class View:
                                                  projmatrix=self.ct["projmatrix"], sh_degree=3, campos=self.ct["campos"], prefiltered=False,
                                                  debug=False)
         self.rasterizer = GaussianRasterizer(settings)
+        # allmap[2:5] as an output tap: the reflection pass's normal gradient reaches the tile backward as its own pointer instead of
+        # through autograd's zero-fill + slice copy + add over the 8-plane image (extension; render() of the package does the same)
+        self.rasterizer.set_output_taps(("normal_view",))
         # what gaussian_renderer.surface_pass reads from a camera
         self.world_view_transform, self.full_proj_transform = self.ct["viewmatrix"], self.ct["projmatrix"]
         self.image_width, self.image_height = W, H
@@ -189,11 +192,11 @@ def main():
 
     def render(view, refl_sink, accumulate):
         ct = view.ct
-        base, radii, allmap, refl_map, gw = view.rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
+        base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
                                                             shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
                                                             scales=scene.p["scales"], rotations=scene.p["rotations"],
                                                             env_scope_mask=scene.mask)
-        final, refl_color, nrm = deferred_reflection(allmap[2:5], base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
+        final, refl_color, nrm = deferred_reflection(normal_view, base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
                                                      grad_sink=refl_sink, accumulate=accumulate,
                                                      async_tail=refl_sink is not None and not args.sync_reflection_tail)
         if base.grad_fn is not None:
@@ -498,10 +501,10 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
         for i, view in enumerate(views):
             view.rasterizer.set_grad_sink(fsink, accumulate=i > 0)
             means2D.grad = None
-            base, radii, allmap, refl_map, gw = view.rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
+            base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
                                                                 shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
                                                                 rotations=st.p["rotations"], env_scope_mask=mask)
-            final, _, rend_normal = deferred_reflection(allmap[2:5], base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
+            final, _, rend_normal = deferred_reflection(normal_view, base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
                                               grad_sink=frsink, accumulate=i > 0, async_tail=not args.sync_reflection_tail)
             # the reference's iteration (train.py:144-196): surface pass of render(), photometric + normal-consistency loss
             surf_depth, surf_normal = surface_pass(allmap, view, 0.0)

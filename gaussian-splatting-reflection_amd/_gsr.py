@@ -51,6 +51,8 @@ def _load():
                                         P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P]
     lib.gsr_surfel_backward_accum.restype = c_int
     lib.gsr_surfel_backward_accum.argtypes = lib.gsr_surfel_backward.argtypes[:-2] + [c_int, c_int, P]
+    lib.gsr_surfel_backward_ex.restype = c_int
+    lib.gsr_surfel_backward_ex.argtypes = lib.gsr_surfel_backward.argtypes[:-2] + [c_int, P, c_int, P]
     lib.gsr_gauss_forward.restype = c_int
     lib.gsr_gauss_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
                                       c_float, c_float, c_int, P, P, P, P, c_int, P, c_int, P]
@@ -149,7 +151,7 @@ def compiled_binding():
 
 PYBIND = compiled_binding()
 
-EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum",
+EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum", "gsr_surfel_backward_ex",
             "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_deferred_reflection_forward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
             "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_normal_loss_scratch_floats", "gsr_normal_loss_forward", "gsr_normal_loss_backward", "gsr_adam_step", "gsr_adam_step_range", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",

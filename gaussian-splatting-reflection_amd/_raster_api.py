@@ -37,10 +37,11 @@ class GradSink:
     (accumulate=False) or adds (accumulate=True) those gradients straight into them and autograd receives None for the
     corresponding inputs: no zero-fill, no `grad += new` pass.  Not a tensor, so autograd passes it through untouched."""
 
-    def __init__(self, tensors, accumulate=False, async_tail=False):
-        self.tensors = dict(tensors)
+    def __init__(self, tensors, accumulate=False, async_tail=False, taps=()):
+        self.tensors = dict(tensors or {})
         self.accumulate = bool(accumulate)
         self.async_tail = bool(async_tail)     # deferred_reflection only: see its docstring
+        self.taps = tuple(taps)                # rasterizer only: output taps of this forward (GaussianRasterizer.set_output_taps)
 
 
 @dataclass
@@ -61,6 +62,7 @@ class Variant:
     optional_grads: Tuple[str, ...]                    # inputs whose gradient is None when they were passed as placeholders
     sinkable: Dict[str, str] = field(default_factory=dict)   # apply() tensor name -> gradient-sink key
     skippable: Dict[str, str] = field(default_factory=dict)  # apply() tensor name -> `unused` key of the _C backward: not computed when the input was a placeholder
+    taps: Dict[str, Tuple[int, int, int, str]] = field(default_factory=dict)   # tap name -> (output index, first plane, last plane + 1, _C backward keyword)
     snapshot_on_debug: bool = False
 
 
@@ -98,6 +100,12 @@ def build_api(v: Variant):
             # non-differentiable ones (radii, gaussian_weights: two P-sized fill dispatches per step that nobody reads)
             ctx.set_materialize_grads(False)
             ctx.out_meta = [(tuple(o.shape), o.dtype, o.device) for o in outputs]
+            # output taps (extension): plane ranges of an output returned as further outputs that ALIAS it.  A consumer that reads the
+            # tap sends its gradient to backward() as a separate argument, and the tile kernel adds it while loading the upstream
+            # planes; through `output[a:b]` autograd would zero-fill a full-size gradient, copy the planes in and add the two images.
+            ctx.taps = sink.taps if sink is not None else ()
+            if ctx.taps:
+                outputs = tuple(outputs) + tuple(outputs[v.taps[n][0]][v.taps[n][1]:v.taps[n][2]] for n in ctx.taps)
             return outputs
 
         @staticmethod
@@ -106,10 +114,13 @@ def build_api(v: Variant):
             kept = ctx.saved_tensors
             saved = dict(zip(v.saved, kept[:len(v.saved)]))
             radii, buffers = kept[len(v.saved)], kept[len(v.saved) + 1:]
+            tap_grads = {v.taps[n][3]: g for n, g in zip(ctx.taps, grad_outputs[len(ctx.out_meta):]) if g is not None}
+            grad_outputs = grad_outputs[:len(ctx.out_meta)]
             grad_outputs = [torch.zeros(m[0], dtype=m[1], device=m[2]) if (g is None and i not in v.nondiff_outputs) else g
                             for i, (g, m) in enumerate(zip(grad_outputs, ctx.out_meta))]
             c_args = v.pack_backward(saved, settings, grad_outputs, ctx.num_rendered, buffers, radii)
-            sink_kw = {} if ctx.grad_sink is None else {"grad_sink": ctx.grad_sink.tensors, "accumulate": ctx.grad_sink.accumulate}
+            sink_kw = {"grad_sink": ctx.grad_sink.tensors, "accumulate": ctx.grad_sink.accumulate} if (ctx.grad_sink and ctx.grad_sink.tensors) else {}
+            sink_kw.update(tap_grads)
             # gradients of inputs that were passed as empty placeholders are dropped below anyway: tell the kernel not to write them
             unused = tuple(key for name, key in v.skippable.items() if saved.get(name) is None or saved[name].numel() == 0)
             if unused:
@@ -150,6 +161,7 @@ def build_api(v: Variant):
             super().__init__()
             self.raster_settings = raster_settings
             self._grad_sink = None
+            self._taps = ()
 
         def set_grad_sink(self, sink, accumulate=False):
             """Extension (not in the reference): route THIS rasterizer's parameter gradients into caller-owned tensors.
@@ -161,6 +173,18 @@ def build_api(v: Variant):
             if sink and not v.sinkable:
                 raise NotImplementedError("this rasterizer variant has no gradient sinks")
             self._grad_sink = GradSink(sink, accumulate) if sink else None
+
+        def set_output_taps(self, names=()):
+            """Extension (not in the reference): forward() returns, after the reference's tuple, one more tensor per name —
+            a plane range of one of the outputs, aliasing it (variant S: "normal_view" = allmap[2:5], what the reference's
+            render() hands to the reflection pass).  Use the tap instead of slicing the output yourself and the gradient it
+            receives travels to the backward kernel as a separate pointer, which adds it to the upstream planes while loading
+            them: no zero-filled full-size gradient, no slice copy, no image-sized add between the two autograd nodes
+            (0.05 ms per 1080p view).  Same values either way."""
+            unknown = [n for n in names if n not in v.taps]
+            if unknown:
+                raise NotImplementedError(f"this rasterizer variant has no output tap(s) {unknown}; available: {sorted(v.taps)}")
+            self._taps = tuple(names)
 
         def markVisible(self, positions):
             """Boolean mask of the points in front of the camera's near plane (frustum test of the rasterizer)."""
@@ -181,7 +205,10 @@ def build_api(v: Variant):
                 t[name] = v.placeholder(name, means3D.device) if value is None and name in PLACEHOLDERS else value
             args = [t[name] for name in v.tensors]
             args.insert(v.settings_pos, self.raster_settings)
-            return rasterize_gaussians(*args, grad_sink=self._grad_sink)
+            ext = self._grad_sink
+            if self._taps:
+                ext = GradSink(ext.tensors if ext else None, ext.accumulate if ext else False, taps=self._taps)
+            return rasterize_gaussians(*args, grad_sink=ext)
 
     PLACEHOLDERS = {"sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp", "env_scope_mask"}
     # give forward() the reference's explicit signature (keyword names and defaults are part of the API)

@@ -863,27 +863,39 @@ struct ReflScratch {
 // Sort of (texel id, pixel) through gsr_sort.hpp (one clear per sort).  17-bit texel ids at L = 128, 19-bit at L = 256: two
 // passes with 9- or 10-bit digits instead of three with 8.  Workgroup shape measured at n = 2 M pairs (whole backward, ms):
 // 256x12 0.361, 512x12 0.320, 1024x4 0.313, 1024x6 0.306, 1024x8 0.297, 1024x12 0.309, 1024x16 0.314.
+// `small` (the tail on the side stream, beside the tile backward): 256-thread workgroups with 8-bit digits.  The tile backward keeps
+// every CU at 16 single-wave workgroups and 152 of its 160 KB of LDS; a 1024-thread pass (39 KB of LDS, 16 waves) can only start on a
+// CU that has drained, i.e. when the tile backward is over, while a 256-thread one (one wave per SIMD, ~13 KB) slips in whenever one
+// of those workgroups retires.  Slower on an empty chip (one more pass, 4x the look-back chain), but hidden.
+#ifndef REFL_SMALL_SORT
+#define REFL_SMALL_SORT 1
+#endif
 static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
-                            bool pre_cleared = false) {
+                            bool pre_cleared = false, bool small = false) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
-	if (temp == nullptr) {   // size query: the larger of the two drivers' needs (the runtime switch never changes a scratch size)
-		size_t own = 0, pub = 0;
+	if (temp == nullptr) {   // size query: the largest of the drivers' needs (neither the runtime switch nor the stream a tail runs on changes a scratch size)
+		size_t own = 0, pub = 0, sm = 0;
 		if (key_bits > 16 && key_bits <= 18) (void)onesweep_sort_pairs<1024, 8, 9>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		else if (key_bits > 18 && key_bits <= 20) (void)onesweep_sort_pairs<1024, 8, 10>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		else (void)onesweep_sort_pairs<1024, 8, 8>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+		(void)onesweep_sort_pairs<256, 8, 8>(nullptr, sm, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		(void)rocprim::radix_sort_pairs(nullptr, pub, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
 		bytes = own > pub ? own : pub;
+		if (sm > bytes) bytes = sm;
 		return hipSuccess;
 	}
 	if (!option_sort_driver())   // gsr_set_option("sort_driver", 0) or an unknown rocPRIM release: the public entry point
 		return rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+	if (small)
+		return onesweep_sort_pairs<256, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
 	if (key_bits > 16 && key_bits <= 18)
 		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
 	if (key_bits > 18 && key_bits <= 20)
 		return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
 	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
 }
-static size_t refl_sort_cleared_bytes(int key_bits, size_t n) {
+static size_t refl_sort_cleared_bytes(int key_bits, size_t n, bool small) {
+	if (small) return onesweep_cleared_bytes<256, 8, 8>(n, 0u, (unsigned)key_bits);
 	if (key_bits > 16 && key_bits <= 18) return onesweep_cleared_bytes<1024, 8, 9>(n, 0u, (unsigned)key_bits);
 	if (key_bits > 18 && key_bits <= 20) return onesweep_cleared_bytes<1024, 8, 10>(n, 0u, (unsigned)key_bits);
 	return onesweep_cleared_bytes<1024, 8, 8>(n, 0u, (unsigned)key_bits);
@@ -911,6 +923,13 @@ extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, 
 // they are enqueued on a library-owned stream that forks from the caller's stream after the pixel kernel and run
 // beside the (VALU-bound) tile backward; gsr_side_join() makes a stream wait for them.  One side stream per device, so
 // successive tails (a batch of views accumulating into one gradient) stay ordered among themselves.
+// Priority of the side stream.  Highest: the tail's small workgroups go first whenever a slot frees up, its look-back chains move
+// and it is over early (measured, interleaved runs of the C3 step: highest 1.917-1.922 ms; default 1.905-1.920 ms in two runs of four but
+// 2.44 / 2.55 ms in the other two — default-priority streams share the runtime's pool of hardware queues and the step then
+// depends on which queue the side stream happened to get; lowest 1.98 ms: the tail only runs once the tile backward has drained).
+#ifndef GSR_SIDE_PRIO
+#define GSR_SIDE_PRIO 1     // 0: default priority; 1: highest; -1: lowest
+#endif
 namespace {
 struct SideStream {
 	hipStream_t stream = nullptr;
@@ -924,9 +943,13 @@ SideStream* side_stream() {   // (g_side_mu held)
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
 	SideStream& s = g_side[dev];
 	if (!s.stream) {
-		// default priority: at the lowest one the tail only got onto the chip when the tile backward had drained and then ran
-		// beside the HBM-bound per-Gaussian backward instead (measured: step 2.102 -> 2.083 ms; preprocess_bwd 0.174 -> 0.195 ms)
+#if GSR_SIDE_PRIO
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, GSR_SIDE_PRIO > 0 ? greatest : least) != hipSuccess) { s.stream = nullptr; return nullptr; }
+#else
 		if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+#endif
 		if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
 			(void)hipStreamDestroy(s.stream);
 			s.stream = nullptr;
@@ -983,7 +1006,8 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 		uint32_t* pix_out = keys_out + rs.n;
 		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
 		const unsigned egrid = (unsigned)((HW + 255) / 256);
-		const size_t clr = refl_sort_cleared_bytes(rs.key_bits, rs.n);
+		const bool small_sort = async_tail && REFL_SMALL_SORT;
+		const size_t clr = refl_sort_cleared_bytes(rs.key_bits, rs.n, small_sort);
 		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
 			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
 			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
@@ -1011,7 +1035,7 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 		{
 		// the tail has its own stage (timed on the stream it runs on): with async_tail it is NOT inside GSR_STAGE_REFL_BWD's events
 		StageTimer tail_timer(GSR_STAGE_REFL_BWD_TAIL, tail);
-		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true));
+		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true, small_sort));
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, tail>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 		auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;

@@ -565,7 +565,7 @@ struct SurfelBwdPix {
 __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, size_t pix, size_t HW, const float* __restrict__ bg,
                                                 const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
                                                 const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
-                                                const float* __restrict__ dL_drefl_map) {
+                                                const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_dnormal_extra) {
 	s.T_final = inside ? final_Ts[pix] : 0.f;
 	s.T = s.T_final;
 	s.last_contributor = inside ? (int)n_contrib[pix] : 0;
@@ -582,6 +582,10 @@ __device__ __forceinline__ void surfel_bwd_init(SurfelBwdPix& s, bool inside, si
 		s.dnzr = mk2(dL_depths[4 * HW + pix], dL_drefl_map[pix]);
 		s.dL_dmedian_depth = dL_depths[5 * HW + pix];
 		dL_dreg = dL_depths[6 * HW + pix];
+		if (dL_dnormal_extra) {   // a second upstream gradient of the normal planes 2..4 (gsr_surfel_backward_ex), added here instead of by a pass over the image
+			s.dn01 += mk2(dL_dnormal_extra[pix], dL_dnormal_extra[HW + pix]);
+			s.dnzr.x += dL_dnormal_extra[2 * HW + pix];
+		}
 	}
 	s.FDr = (inside ? final_Ts[HW + pix] : 0.f) * dL_dreg;
 	s.FD2r = (inside ? final_Ts[2 * HW + pix] : 0.f) * dL_dreg;
@@ -729,7 +733,8 @@ __device__ __forceinline__ void
 surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                             const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,
                             const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
-                            const float* __restrict__ dL_drefl_map, float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask) {
+                            const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_dnormal_extra, float* __restrict__ acc,
+                            const unsigned long long* __restrict__ blend_mask) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
@@ -748,14 +753,14 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 
 	__shared__ float s_slab[(S_CAP + 2) * S_ACC_F];     // [slot][20 floats]; slot S_CAP takes the stores of rows that have run out, slot S_CAP + 1 stays zero
 	__shared__ float4 s_rec[S_WBATCH * S_REC_F4];       // records of the batch's blended entries (indexed by position in the batch)
-	__shared__ uint32_t s_cw[S_WBATCH];                 // per entry of the chunk (compacted): the slab slot of each of the four rows, one byte each
-	__shared__ uint32_t s_cid[S_WBATCH];                // its surfel id
+	__shared__ uint32_t s_cw[S_WBATCH];                 // per entry of the chunk (compacted): the slab slot of each of the four rows (6 bits each) and, from bit 24, its batch position
 #if GSR_BWD_LIST
-	__shared__ uint8_t s_list[4 * S_WBATCH];            // per row: the batch positions of its entries in the order it visits them (last first)
+	__shared__ uint8_t s_list[64];                      // by slab slot (a row's slots are consecutive, in the order it visits them: last entry first): the batch position
 #endif
+	static_assert(S_CAP + 1 < 64, "slab slots are packed into 6 bits");
 
 	SurfelBwdPix st;
-	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map);
+	surfel_bwd_init(st, inside, pix, HW, bg, final_Ts, n_contrib, dL_dpixels, dL_depths, dL_drefl_map, dL_dnormal_extra);
 	st.pixs = mk2(-pixv.y, pixv.x);
 	int wave_last = st.last_contributor;
 #pragma unroll
@@ -783,7 +788,9 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 		if ((any >> lane) & 1ull) {
 			id = point_list[range.x + (uint32_t)(b * S_WBATCH + lane)];
 			const float4* q = rec + (size_t)id * S_REC_F4;
-			const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4];
+			const float4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3];
+			float4 r4 = q[4];
+			r4.w = __uint_as_float(id);     // the record's last float (the env-scope mask) is not read by the backward: the flush finds the surfel id there
 			float4* d = s_rec + lane * S_REC_F4;
 			d[0] = r0; d[1] = r1; d[2] = r2; d[3] = r3; d[4] = r4;
 		}
@@ -817,14 +824,13 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 				const uint32_t s2 = ((c2 >> lane) & 1ull) ? (uint32_t)(n0 + n1 + __popcll(c2 & gt)) : (uint32_t)(S_CAP + 1);
 				const uint32_t s3 = ((c3 >> lane) & 1ull) ? (uint32_t)(n0 + n1 + n2 + __popcll(c3 & gt)) : (uint32_t)(S_CAP + 1);
 				const int k = __popcll(call & lt);
-				s_cw[k] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
-				s_cid[k] = id;
+				s_cw[k] = s0 | (s1 << 6) | (s2 << 12) | (s3 << 18) | ((uint32_t)lane << 24);
 #if GSR_BWD_LIST
-				// the row's visiting order is its slab-slot order: entry number (slot - first slot of the row) of row r is this position
+				// the row's visiting order is its slab-slot order
 				if ((c0 >> lane) & 1ull) s_list[s0] = (uint8_t)lane;
-				if ((c1 >> lane) & 1ull) s_list[S_WBATCH + s1 - n0] = (uint8_t)lane;
-				if ((c2 >> lane) & 1ull) s_list[2 * S_WBATCH + s2 - n0 - n1] = (uint8_t)lane;
-				if ((c3 >> lane) & 1ull) s_list[3 * S_WBATCH + s3 - n0 - n1 - n2] = (uint8_t)lane;
+				if ((c1 >> lane) & 1ull) s_list[s1] = (uint8_t)lane;
+				if ((c2 >> lane) & 1ull) s_list[s2] = (uint8_t)lane;
+				if ((c3 >> lane) & 1ull) s_list[s3] = (uint8_t)lane;
 #endif
 			}
 			__syncthreads();
@@ -836,10 +842,10 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 			// (round 3) the row reads its next entry from the list the staging lanes wrote (one ds_read_u8) instead of walking its bit mask
 			// (two v_ffbl, a 64-bit x & (x - 1), min / sub / or: 11 VALU instructions per iteration in a loop bound by VALU issue)
 			const int nrow = row == 0 ? n0 : (row == 1 ? n1 : (row == 2 ? n2 : n3));
-			const uint8_t* mylist = s_list + row * S_WBATCH;
 #endif
+			const uint32_t rowbase = (uint32_t)(row == 0 ? 0 : (row == 1 ? n0 : (row == 2 ? n0 + n1 : n0 + n1 + n2)));   // first slab slot of the row
 			// byte offset of the row's next slab slot
-			uint32_t myslot = (uint32_t)(row == 0 ? 0 : (row == 1 ? n0 : (row == 2 ? n0 + n1 : n0 + n1 + n2))) * (S_ACC_F * 4u) + slab_lane;
+			uint32_t myslot = rowbase * (S_ACC_F * 4u) + slab_lane;
 #pragma unroll GSR_BWD_UNROLL
 			for (int t = 0; t < nmax; t++) {
 #if !GSR_BWD_LIST
@@ -850,7 +856,7 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 				left &= left - 1ull;
 #else
 				const lmask valid = LMASK(t < nrow);
-				const uint32_t j = selmu(valid, (uint32_t)mylist[min(t, S_WBATCH - 1)], jany);
+				const uint32_t j = selmu(valid, (uint32_t)s_list[min(rowbase + (uint32_t)t, 63u)], jany);
 #endif
 				const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + __umul24(j, S_REC_F4 * 16u));   // (24-bit multiply: full rate)
 				const SurfelRec R{q[0], q[1], q[2], q[3], q[4]};
@@ -873,12 +879,13 @@ surfel_render_bwd_rows_body(const uint2* __restrict__ ranges, const uint32_t* __
 			for (int k0 = 0; k0 < nent; k0 += 3) {
 				const uint32_t k = (uint32_t)k0 + fl_k;
 				if (fl_on && k < (uint32_t)nent) {
-					const uint32_t w = s_cw[k], eid = s_cid[k];
+					const uint32_t w = s_cw[k];
+					const uint32_t eid = __float_as_uint(s_rec[(w >> 24) * S_REC_F4 + 4].w);
 					const char* base = slab_b + fl_d * 4u;
-					const float a0 = *reinterpret_cast<const float*>(base + (w & 0xFFu) * (S_ACC_F * 4u));
-					const float a1 = *reinterpret_cast<const float*>(base + ((w >> 8) & 0xFFu) * (S_ACC_F * 4u));
-					const float a2 = *reinterpret_cast<const float*>(base + ((w >> 16) & 0xFFu) * (S_ACC_F * 4u));
-					const float a3 = *reinterpret_cast<const float*>(base + (w >> 24) * (S_ACC_F * 4u));
+					const float a0 = *reinterpret_cast<const float*>(base + (w & 0x3Fu) * (S_ACC_F * 4u));
+					const float a1 = *reinterpret_cast<const float*>(base + ((w >> 6) & 0x3Fu) * (S_ACC_F * 4u));
+					const float a2 = *reinterpret_cast<const float*>(base + ((w >> 12) & 0x3Fu) * (S_ACC_F * 4u));
+					const float a3 = *reinterpret_cast<const float*>(base + ((w >> 18) & 0x3Fu) * (S_ACC_F * 4u));
 					if (!(dev_flags & 1)) atomicAdd(fl_acc + (size_t)eid * S_ACC_F, (a0 + a1) + (a2 + a3));
 				}
 			}
@@ -893,9 +900,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSR_BWD
 surfel_render_bwd_rows_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float* __restrict__ bg, const float4* __restrict__ rec, int dev_flags, const float* __restrict__ final_Ts,
                               const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_depths,
-                              const float* __restrict__ dL_drefl_map, float* __restrict__ acc, const unsigned long long* __restrict__ blend_mask) {
+                              const float* __restrict__ dL_drefl_map, const float* __restrict__ dL_dnormal_extra, float* __restrict__ acc,
+                              const unsigned long long* __restrict__ blend_mask) {
 	surfel_render_bwd_rows_body(ranges, tile_order, point_list, W, H, tiles_x, ntiles, bg, rec, dev_flags, final_Ts, n_contrib, dL_dpixels, dL_depths,
-	                            dL_drefl_map, acc, blend_mask);
+	                            dL_drefl_map, dL_dnormal_extra, acc, blend_mask);
 }
 
 // quat_to_rotmat_vjp (DSR auxiliary.h:242-286)
@@ -1170,14 +1178,14 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 	return R;
 }
 
-extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+extern "C" int gsr_surfel_backward_ex(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                    const float* shs, const float* colors_precomp, const float* refl_strengths, const float* scales,
                                    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
                                    void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
                                    const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
                                    float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
-                                   float* dL_drot, int accumulate, int debug, void* stream_) {
+                                   float* dL_drot, int accumulate, const float* dL_dnormal_extra, int debug, void* stream_) {
 	(void)colors_precomp; (void)refl_strengths; (void)scale_modifier; (void)transMat_precomp;
 	hipStream_t stream = (hipStream_t)stream_;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_surfel_backward: invalid size"); return GSR_E_INVALID; }
@@ -1203,8 +1211,8 @@ extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		surfel_render_bwd_rows_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,
-		                                                         option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, geom.acc,
-		                                                         bin.blend_mask); }
+		                                                         option_dev(), img.final_T, img.n_contrib, dL_dpix, dL_dothers, dL_drefl_strength_map, dL_dnormal_extra,
+		                                                         geom.acc, bin.blend_mask); }
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
@@ -1225,8 +1233,22 @@ extern "C" int gsr_surfel_backward(int P, int D, int M, int R, const float* back
                                    const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
                                    float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
                                    float* dL_drot, int debug, void* stream_) {
-	return gsr_surfel_backward_accum(P, D, M, R, background, width, height, means3D, shs, colors_precomp, refl_strengths, scales, scale_modifier, rotations,
-	                                 transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
-	                                 dL_dpix, dL_dothers, dL_drefl_strength_map, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths, dL_dmean3D,
-	                                 dL_dtransMat, dL_dsh, dL_dscale, dL_drot, 0, debug, stream_);
+	return gsr_surfel_backward_ex(P, D, M, R, background, width, height, means3D, shs, colors_precomp, refl_strengths, scales, scale_modifier, rotations,
+	                              transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+	                              dL_dpix, dL_dothers, dL_drefl_strength_map, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths, dL_dmean3D,
+	                              dL_dtransMat, dL_dsh, dL_dscale, dL_drot, 0, nullptr, debug, stream_);
+}
+
+extern "C" int gsr_surfel_backward_accum(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* refl_strengths, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                                   void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                                   const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor,
+                                   float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale,
+                                   float* dL_drot, int accumulate, int debug, void* stream_) {
+	return gsr_surfel_backward_ex(P, D, M, R, background, width, height, means3D, shs, colors_precomp, refl_strengths, scales, scale_modifier, rotations,
+	                              transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+	                              dL_dpix, dL_dothers, dL_drefl_strength_map, dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_drefl_strengths, dL_dmean3D,
+	                              dL_dtransMat, dL_dsh, dL_dscale, dL_drot, accumulate, nullptr, debug, stream_);
 }

@@ -66,7 +66,8 @@ def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_streng
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_others, dL_dout_refl_strength_map, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, grad_sink=None, accumulate=False, unused=()):
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *, grad_sink=None, accumulate=False, unused=(),
+                                 extra_normal_grad=None):
     """Same positional arguments and return tuple as the reference's `_C.rasterize_gaussians_backward`.  Keyword-only
     extension: `grad_sink` maps any of means3D (P,3), shs (P,M,3), opacities (P,1), scales (P,2), rotations (P,4),
     refl_strengths (P,1) to a preallocated contiguous float32 tensor (e.g. views of one flat all-reduce / optimizer buffer,
@@ -74,7 +75,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     straight into them and the corresponding entries of the return tuple are those same tensors.  The sink belongs to
     this call: there is no module-level state.  `unused` (keyword-only extension, what the autograd wrapper passes): any of "colors",
     "transMat" — gradients of inputs the caller did not supply (shs instead of colors_precomp, scales / rotations instead of
-    transMat_precomp); the kernel does not write them and the tuple holds empty tensors in their place."""
+    transMat_precomp); the kernel does not write them and the tuple holds empty tensors in their place.
+    `extra_normal_grad` (keyword-only extension): float32 (3,H,W), a second upstream gradient of planes 2..4 of the `others`
+    output (the blended view-space normal) that the tile kernel adds to dL_dout_others[2:5] while loading it
+    (gsr_surfel_backward_ex) — what the output tap `normal_view` of GaussianRasterizer receives."""
     M = sh.size(1) if sh.numel() != 0 else 0
     if grad_sink:
         unknown = set(grad_sink) - SINKABLE
@@ -86,7 +90,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     unused = frozenset(unused)
     if unused - {"colors", "transMat"} or ("colors" in unused and sh.numel() == 0) or ("transMat" in unused and scales.numel() == 0):
         raise ValueError("unused: 'colors' needs shs as the colour input, 'transMat' needs scales / rotations; got %r" % (sorted(unused),))
-    if _gsr.PYBIND is not None and not grad_sink:
+    if extra_normal_grad is not None:
+        if tuple(extra_normal_grad.shape) != (3,) + tuple(dL_dout_color.shape[1:]) or extra_normal_grad.device != means3D.device:
+            raise ValueError(f"extra_normal_grad: expected (3, H, W) = {(3,) + tuple(dL_dout_color.shape[1:])} on {means3D.device}, "
+                             f"got {tuple(extra_normal_grad.shape)} on {extra_normal_grad.device}")
+    if _gsr.PYBIND is not None and not grad_sink and extra_normal_grad is None:
         return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
             background, means3D, radii, colors, refl_strengths, scales, rotations, float(scale_modifier), transMat_precomp, viewmatrix, projmatrix,
             float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_others,
@@ -132,13 +140,14 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
                 f32c(campos, "campos"), f32c(dL_dout_color, "dL_dout_color"), f32c(dL_dout_others, "dL_dout_others"),
                 f32c(dL_dout_refl_strength_map, "dL_dout_refl_strength_map"), radii.contiguous()]
         bg, m3, shc, col, refl, sca, rot, tmp, vm, pm, cp, gcol, goth, grefl, rad = keep
+        gnx = f32c(extra_normal_grad, "extra_normal_grad") if extra_normal_grad is not None else None
         with torch.cuda.device(dev):
-            check(lib.gsr_surfel_backward_accum(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
+            check(lib.gsr_surfel_backward_ex(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
                                           float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm), ptr(cp), float(tan_fovx),
                                           float(tan_fovy), ptr(rad), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), ptr(gcol),
                                           ptr(goth), ptr(grefl), ptr(dL_dmeans2D), ptr(dL_dnormal), ptr(dL_dopacity), ptr(dL_dcolors),
                                           ptr(dL_drefl), ptr(dL_dmeans3D), ptr(dL_dtransMat), ptr(dL_dsh), ptr(dL_dscales),
-                                          ptr(dL_drotations), int(bool(accumulate)), int(bool(debug)), stream_ptr(dev)), "gsr_surfel_backward")
+                                          ptr(dL_drotations), int(bool(accumulate)), ptr(gnx), int(bool(debug)), stream_ptr(dev)), "gsr_surfel_backward")
     return dL_dmeans2D, dL_dcolors, dL_drefl, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -59,6 +59,7 @@ _VARIANT = Variant(
     sinkable={"means3D": "means3D", "sh": "shs", "opacities": "opacities", "scales": "scales", "rotations": "rotations",
               "refl_strengths": "refl_strengths"},
     skippable={"colors_precomp": "colors", "cov3Ds_precomp": "transMat"},
+    taps={"normal_view": (2, 2, 5, "extra_normal_grad")},        # allmap[2:5], the reflection pass's input
     snapshot_on_debug=True)
 
 GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)

@@ -287,6 +287,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     raster_sink, refl_sink, accumulate, async_tail = _sinks(pipe)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
     rasterizer.set_grad_sink(raster_sink, accumulate)
+    # allmap[2:5] as an output tap: the gradient of its consumer below reaches the tile backward as a pointer of its own instead
+    # of being summed into a full-size allmap gradient by autograd (same values; GaussianRasterizer.set_output_taps)
+    rasterizer.set_output_taps(("normal_view",))
     if env_scope_radius > 0.0:
         centre = torch.tensor([float(c) for c in env_scope_center], device=dev)
         env_scope_mask = ((xyz - centre[None]) ** 2).sum(dim=-1) < env_scope_radius ** 2
@@ -298,7 +301,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     else:
         scales, rotations = pc.get_scaling, pc.get_rotation
     shs = pc.get_features if override_color is None else None       # SH evaluation always happens in the rasterizer
-    base_color, radii, allmap, refl_strength_map, gaussian_weights = rasterizer(
+    base_color, radii, allmap, refl_strength_map, gaussian_weights, normal_view = rasterizer(
         means3D=xyz, means2D=means2D, shs=shs, colors_precomp=override_color, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask)
 
@@ -308,10 +311,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
            "rend_dist": allmap[6:7], "surf_depth": surf_depth, "surf_normal": surf_normal, "gaussian_weights": gaussian_weights,
            "env_scope_mask": allmap[7:8]}
     if initial_stage:
-        out["rend_normal"] = shading_normal(allmap[2:5], v.world_view_transform, v.HWK, v.R, v.T)
+        out["rend_normal"] = shading_normal(normal_view, v.world_view_transform, v.HWK, v.R, v.T)
         out["render"] = base_color
         return out
-    final_image, refl_color, rend_normal = deferred_reflection(allmap[2:5], base_color, refl_strength_map, pc.get_envmap,
+    final_image, refl_color, rend_normal = deferred_reflection(normal_view, base_color, refl_strength_map, pc.get_envmap,
                                                                v.world_view_transform, v.HWK, v.R, v.T, grad_sink=refl_sink,
                                                                accumulate=accumulate, async_tail=async_tail and bool(refl_sink))
     out.update({"rend_normal": rend_normal, "render": final_image, "refl_strength_map": refl_strength_map, "refl_color_map": refl_color,

@@ -101,6 +101,21 @@ int gsr_surfel_backward_accum(int P, int D, int M, int R, const float* backgroun
                         const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
                         float* dL_dcolor, float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat,
                         float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate, int debug, void* stream);
+/* Extension: one more upstream gradient.  dL_dnormal_extra float[3,H,W] or NULL is a SECOND gradient of the blended
+ * normal planes (planes 2..4 of out_others) — the one the deferred-reflection pass returns for its normal_view input
+ * (gaussian_renderer/__init__.py:25-35 of the reference reads allmap[2:5]) — and the tile kernel adds it to planes 2..4 of
+ * dL_dothers as it loads them.  Plain autograd sums the two with a zero-fill, a slice copy and an add over the
+ * 8-plane image (0.05 ms per 1080p view); here that pass does not exist.  NULL: gsr_surfel_backward_accum. */
+int gsr_surfel_backward_ex(int P, int D, int M, int R, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* refl_strengths, const float* scales, float scale_modifier, const float* rotations,
+                        const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer,
+                        void* binning_buffer, void* image_buffer, const float* dL_dpix, const float* dL_dothers,
+                        const float* dL_drefl_strength_map, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+                        float* dL_dcolor, float* dL_drefl_strengths, float* dL_dmean3D, float* dL_dtransMat,
+                        float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate,
+                        const float* dL_dnormal_extra, int debug, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Variant G — 3D Gaussians with EWA projection, anti-aliasing and inverse depth.  Replaces

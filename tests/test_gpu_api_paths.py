@@ -384,3 +384,71 @@ def test_sort_drivers_agree_bit_for_bit(P, W, H, mu):
     for k in ("color", "allmap", "radii"):
         np.testing.assert_array_equal(o1[k], o0[k], err_msg=k)
     assert rel_maxnorm(g1, g0) <= 1e-5      # same sorted order; LDS / global float atomics inside the combine differ in order
+
+
+def test_normal_view_tap_equals_the_slice():
+    """Extension: GaussianRasterizer.set_output_taps(("normal_view",)) returns allmap[2:5] as a sixth output that aliases the
+    allmap tensor; the gradient its consumer (the reflection pass) sends back reaches the tile backward as a pointer of its own
+    (gsr_surfel_backward_ex) and is added to the upstream planes while they are loaded.  Same forward values, and the same
+    parameter gradients as slicing allmap by hand — with plain autograd, with a gradient sink, and when only the tap carries a
+    gradient (no upstream gradient for allmap at all)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as GS_G, GaussianRasterizer as GR_G
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussian_renderer import deferred_reflection
+    from gsr_dist import FlatGrads
+    P, W, H, L = 4000, 192, 128, 16
+    sc = S.make_scene(P, "S", seed=31, mu=-2.7)
+    tex, fail = S.make_cubemap(L, 3, 31)
+    cam = S.make_camera(W, H)
+    ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
+    g = S.make_upstream_grads(H, W, 31)
+    g_final, g_allmap = torch.from_numpy(g["dL_dcolor"]).cuda(), torch.from_numpy(g["dL_dplanes"]).cuda()
+    names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
+    settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                             bg=torch.zeros(3, device="cuda"), scale_modifier=1.0, viewmatrix=ct["viewmatrix"],
+                                             projmatrix=ct["projmatrix"], sh_degree=3, campos=ct["campos"], prefiltered=False, debug=False)
+
+    class Env:
+        params = {"Cubemap_texture": torch.from_numpy(tex).cuda().requires_grad_(True), "Cubemap_failv": torch.from_numpy(fail).cuda().requires_grad_(True)}
+
+    def run(tap, with_allmap_grad=True, sink=False):
+        p = {k: torch.from_numpy(sc[k]).cuda().requires_grad_(True) for k in names}
+        rast = GaussianRasterizer(settings)
+        fg = None
+        if sink:
+            fg = FlatGrads(p)
+            fg.flat.fill_(float("nan"))
+            rast.set_grad_sink(fg.sink())
+        if tap:
+            rast.set_output_taps(("normal_view",))
+        means2D = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        out = rast(means3D=p["means3D"], means2D=means2D, opacities=p["opacities"], shs=p["shs"], refl_strengths=p["refl_strengths"],
+                   scales=p["scales"], rotations=p["rotations"], env_scope_mask=torch.from_numpy(sc["env_scope_mask"]).cuda())
+        assert len(out) == (6 if tap else 5)
+        base, radii, allmap, refl_map, gw = out[:5]
+        nv = out[5] if tap else allmap[2:5]
+        if tap:
+            assert nv.data_ptr() == allmap[2:5].data_ptr() and tuple(nv.shape) == (3, H, W)     # an alias, not a copy
+        final, _, _ = deferred_reflection(nv, base, refl_map, Env, ct["viewmatrix"], (H, W, cam["K"]), ct["R"], ct["T"])
+        if with_allmap_grad:
+            torch.autograd.backward([final, allmap], [g_final, g_allmap])
+        else:
+            torch.autograd.backward([final], [g_final])
+        grads = {k: (fg.view(k) if sink else p[k].grad).detach().cpu().numpy().copy() for k in names}
+        grads["means2D"] = means2D.grad.cpu().numpy().copy()
+        return final.detach().cpu().numpy(), grads
+
+    for kw in (dict(), dict(with_allmap_grad=False), dict(sink=True)):
+        f0, g0 = run(False, **kw)
+        f1, g1 = run(True, **kw)
+        assert np.array_equal(f0, f1)
+        for k in g0:
+            assert np.isfinite(g1[k]).all(), (kw, k)
+            assert np.abs(g0[k]).max() > 0, (kw, k)
+            assert rel_maxnorm(g1[k], g0[k]) <= 5e-5, (kw, k)          # float atomics: arrival order differs run to run
+    with pytest.raises(NotImplementedError):
+        GR_G(GS_G(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device="cuda"), scale_modifier=1.0,
+                  viewmatrix=ct["viewmatrix"], projmatrix=ct["projmatrix"], sh_degree=3, campos=ct["campos"], prefiltered=False, debug=False,
+                  antialiasing=False)).set_output_taps(("normal_view",))
+    with pytest.raises(NotImplementedError):
+        GaussianRasterizer(settings).set_output_taps(("depth",))

@@ -58,6 +58,18 @@ def test_gauss_rasterizer_argument_errors(hip_lib_built):
                                0.5, 0.5, 8, 8, torch.zeros(0), 0, torch.zeros(3), False, False, False)
 
 
+def test_output_taps_are_a_surfel_only_extension(hip_lib_built):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings as SG, GaussianRasterizer as RG
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    r = GaussianRasterizer(_settings(GaussianRasterizationSettings))
+    r.set_output_taps(("normal_view",))
+    r.set_output_taps(())
+    with pytest.raises(NotImplementedError, match="no output tap"):
+        r.set_output_taps(("depth",))
+    with pytest.raises(NotImplementedError, match="no output tap"):
+        RG(_settings(SG, antialiasing=False)).set_output_taps(("normal_view",))
+
+
 def test_cubemap_encoder_host_side(hip_lib_built):
     from cubemapencoder import CubemapEncoder
     enc = CubemapEncoder(output_dim=3, resolution=8)
