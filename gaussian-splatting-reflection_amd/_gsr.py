@@ -76,9 +76,9 @@ def _load():
     lib.gsr_deferred_reflection_backward_accum.restype = c_int
     lib.gsr_deferred_reflection_backward_accum.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, P]
     lib.gsr_deferred_reflection_backward_ex.restype = c_int
-    lib.gsr_deferred_reflection_backward_ex.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P, P]
+    lib.gsr_deferred_reflection_backward_ex.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P, P, P]
     lib.gsr_deferred_reflection_forward_ex.restype = c_int
-    lib.gsr_deferred_reflection_forward_ex.argtypes = lib.gsr_deferred_reflection_forward.argtypes[:-1] + [P, P]
+    lib.gsr_deferred_reflection_forward_ex.argtypes = lib.gsr_deferred_reflection_forward.argtypes[:-1] + [P, P, P]
     lib.gsr_side_join.restype = c_int
     lib.gsr_side_join.argtypes = [P]
     lib.gsr_normal_world_forward.restype = c_int
@@ -171,6 +171,8 @@ _side_held = {}          # device index -> tensors the side stream of THAT devic
 def side_hold(*tensors):
     """Keeps device tensors alive that work on the library's side stream still reads (see side_join)."""
     for t in tensors:
+        if t is None:
+            continue
         _side_held.setdefault(t.device.index if t.device.index is not None else torch.cuda.current_device(), []).append(t)
 
 

@@ -365,10 +365,11 @@ __global__ void __launch_bounds__(256)
 deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
                          const float* __restrict__ cam, const float* __restrict__ cubemap, const float4* __restrict__ rgba,
                          const float* __restrict__ fail_value, int L, int W, int H, float* __restrict__ out_final, float* __restrict__ out_refl,
-                         float* __restrict__ out_nworld) {
+                         float* __restrict__ out_nworld, uint32_t* __restrict__ sort_keys, uint32_t no_key) {
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (pix >= HW) return;
+	uint32_t key = no_key;
 	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
 	// loads that do not depend on the reflected direction are issued together with the normal (one memory round trip less
 	// per wave; the kernel is a chain of dependent round trips at five waves per SIMD)
@@ -391,7 +392,11 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 #pragma unroll
 		for (int ch = 0; ch < 3; ch++)
 			c[ch] = (1 - s.ky) * ((1 - s.kx) * cv[0][ch] + s.kx * cv[1][ch]) + s.ky * ((1 - s.kx) * cv[2][ch] + s.kx * cv[3][ch]);
+		// sort key of the backward's footprint record (deferred_refl_bwd_entries_kernel): the texel of the upper-left corner when the 2x2
+		// footprint lies inside one face.  It depends on forward data only, so the sort can run beside the backward's pixel kernel.
+		if (s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1) key = (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
 	}
+	if (sort_keys) sort_keys[pix] = key;
 	const float bs[3] = {b0, b1, b2};
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
@@ -549,8 +554,8 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
                                  int W, int H, const float* __restrict__ g_final, const float* __restrict__ g_refl_color,
                                  const float* __restrict__ g_nworld, float* __restrict__ g_normal_view, float* __restrict__ g_base,
                                  float* __restrict__ g_strength, float* __restrict__ g_fail, float* __restrict__ g_scratch,
-                                 ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, uint32_t no_key, void* sort_clear,
-                                 size_t sort_clear_bytes) {
+                                 ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_fwd, uint32_t no_key,
+                                 void* sort_clear, size_t sort_clear_bytes) {
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	sort_clear_region(sort_clear, sort_clear_bytes, pix, (size_t)gridDim.x * 256u);   // look-back state of the sort that follows
@@ -613,7 +618,12 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 		}
 	}
 	// flag == 0 already implies the unclamped 2x2 block; the corner test keeps the record format honest regardless
-	const bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
+	bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
+	// keys_fwd: the forward kernel already wrote the sort keys (same arithmetic on the same inputs) and the sort may be running beside this
+	// kernel.  Its key decides whether the pixel has a record; should the two kernels ever disagree, the pixel goes through the rim
+	// path below and its record, if the sort expects one, is zeros — nothing is lost or read uninitialised.
+	const uint32_t kf = keys_fwd ? keys_fwd[p] : no_key;
+	if (keys_fwd) interior = interior && kf == (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
 	{
 		// rim pixels (~2/L of all, about one per wave): the wave serves them one at a time.  The pixel's corner texels and
 		// weights travel through SGPRs and lanes 0..11 each add one (corner, channel) value, so a rim pixel costs one atomic
@@ -654,8 +664,12 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 			float* f = reinterpret_cast<float*>(footprints + pix);
 			*reinterpret_cast<float4*>(f) = make_float4(graw[0], graw[1], graw[2], s.kx);
 			f[4] = s.ky;
+		} else if (kf != no_key) {
+			float* f = reinterpret_cast<float*>(footprints + pix);
+			*reinterpret_cast<float4*>(f) = make_float4(0.f, 0.f, 0.f, 0.f);
+			f[4] = 0.f;
 		}
-		keys[pix] = interior ? t00 : no_key;
+		if (!keys_fwd) keys[pix] = interior ? t00 : no_key;
 	}
 	g_strength[p] = gs;
 	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
@@ -825,7 +839,7 @@ extern "C" int gsr_cubemap_backward(const float* grad_outputs, const float* inpu
 extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                   const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                   float* out_final, float* out_refl_color, float* out_normal_world, float* cubemap_rgba,
-                                                  void* stream_) {
+                                                  uint32_t* sort_keys, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !out_final ||
 	    !out_refl_color || !out_normal_world || L == 0 || ((uintptr_t)cubemap_rgba & 15) != 0) {
@@ -839,10 +853,10 @@ extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, cons
 		float4* rgba = reinterpret_cast<float4*>(cubemap_rgba);
 		cubemap_interleave_kernel<<<(unsigned)((6 * (size_t)L * L + 255) / 256), 256, 0, stream>>>(cubemap, rgba, (int)L);
 		deferred_refl_fwd_kernel<true><<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, rgba, fail_value, (int)L, width, height,
-		                                                        out_final, out_refl_color, out_normal_world);
+		                                                        out_final, out_refl_color, out_normal_world, sort_keys, (uint32_t)(6 * (size_t)L * L));
 	} else {
 		deferred_refl_fwd_kernel<false><<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width, height,
-		                                                         out_final, out_refl_color, out_normal_world);
+		                                                         out_final, out_refl_color, out_normal_world, sort_keys, (uint32_t)(6 * (size_t)L * L));
 	}
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
@@ -851,7 +865,7 @@ extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const f
                                                const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                float* out_final, float* out_refl_color, float* out_normal_world, void* stream_) {
 	return gsr_deferred_reflection_forward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, out_final, out_refl_color,
-	                                          out_normal_world, nullptr, stream_);
+	                                          out_normal_world, nullptr, nullptr, stream_);
 }
 
 // Scratch layout of the sorted-footprint backward (floats): [texel staging ntex*4][fail-value gradient 4][pad 4][footprints 8n][keys_in n][keys_out n][pixels_out n]
@@ -870,7 +884,7 @@ struct ReflScratch {
 #ifndef REFL_SMALL_SORT
 #define REFL_SMALL_SORT 1
 #endif
-static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
+static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
                             bool pre_cleared = false, bool small = false) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
 	if (temp == nullptr) {   // size query: the largest of the drivers' needs (neither the runtime switch nor the stream a tail runs on changes a scratch size)
@@ -933,7 +947,7 @@ extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, 
 namespace {
 struct SideStream {
 	hipStream_t stream = nullptr;
-	hipEvent_t fork = nullptr, done = nullptr;
+	hipEvent_t fork = nullptr, fork2 = nullptr, done = nullptr;
 	bool recorded = false;      // `done` has been recorded at least once (an event that was never recorded must not be waited on)
 };
 std::mutex g_side_mu;
@@ -950,7 +964,8 @@ SideStream* side_stream() {   // (g_side_mu held)
 #else
 		if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
 #endif
-		if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+		if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.fork2, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
 			(void)hipStreamDestroy(s.stream);
 			s.stream = nullptr;
 			return nullptr;
@@ -976,7 +991,7 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
                                                    const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                    float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
                                                    float* scratch, size_t scratch_floats, int accumulate, int async_tail, const float* cubemap_rgba,
-                                                   void* stream_) {
+                                                   const uint32_t* sort_keys, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
 	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
@@ -1006,41 +1021,59 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 		uint32_t* pix_out = keys_out + rs.n;
 		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
 		const unsigned egrid = (unsigned)((HW + 255) / 256);
-		const bool small_sort = async_tail && REFL_SMALL_SORT;
+		// sort_keys: the forward already wrote the keys (gsr_deferred_reflection_forward_ex), so the sort depends on nothing this call
+		// computes: with async_tail it forks BEFORE the pixel kernel and runs beside it (an HBM- and latency-bound kernel without LDS: the
+		// 1024-thread passes find room at once) and only the combine waits for the records.  Without them the sort follows the pixel
+		// kernel and, on the side stream, has to share the chip with the tile backward: the small shape then (see refl_sort).
+		const bool small_sort = async_tail && !sort_keys && REFL_SMALL_SORT;
 		const size_t clr = refl_sort_cleared_bytes(rs.key_bits, rs.n, small_sort);
-		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
-			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
-			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
-			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc, scratch, fp,
-			                                                                 keys_in, (uint32_t)ntex, sort_temp, clr);
-		else
-			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
-			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc,
-			                                                                  scratch, fp, keys_in, (uint32_t)ntex, sort_temp, clr);
-		// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
-		st_.reset();
 		hipStream_t tail = stream;
 		SideStream* side = nullptr;
 		std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
 		if (async_tail) {
 			lk.lock();
 			side = side_stream();
+			if (side) tail = side->stream;
+		}
+		size_t sb = rs.sort_bytes;
+		std::unique_ptr<StageTimer> tail_timer;     // GSR_STAGE_REFL_BWD_TAIL is timed on the stream it runs on: with async_tail NOT inside GSR_STAGE_REFL_BWD's events
+		if (sort_keys) {
 			if (side) {
 				GSR_HIP_CHECK(hipEventRecord(side->fork, stream));
 				GSR_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-				tail = side->stream;
 			}
+			tail_timer = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD_TAIL, tail);
+			GSR_HIP_CHECK(hipMemsetAsync(sort_temp, 0, clr, tail));
+			GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, sort_keys, keys_out, pix_out, rs.n, tail, true, false));
 		}
-		size_t sb = rs.sort_bytes;
+		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
+			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
+			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
+			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc, scratch, fp,
+			                                                                 keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : sort_temp, sort_keys ? 0 : clr);
+		else
+			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
+			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc,
+			                                                                  scratch, fp, keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : sort_temp,
+			                                                                  sort_keys ? 0 : clr);
+		// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
+		st_.reset();
+		if (side) {     // the combine needs the records (and, without forward keys, the sort needs the keys) the pixel kernel just wrote
+			hipEvent_t ev = sort_keys ? side->fork2 : side->fork;
+			GSR_HIP_CHECK(hipEventRecord(ev, stream));
+			GSR_HIP_CHECK(hipStreamWaitEvent(side->stream, ev, 0));
+		}
+		if (!sort_keys) {
+			tail_timer = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD_TAIL, tail);
+			GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true, small_sort));
+		}
 		{
-		// the tail has its own stage (timed on the stream it runs on): with async_tail it is NOT inside GSR_STAGE_REFL_BWD's events
-		StageTimer tail_timer(GSR_STAGE_REFL_BWD_TAIL, tail);
-		GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true, small_sort));
 		const size_t per_wg = (size_t)256 * REFL_CHUNK;
 		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, tail>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
 		auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
 		unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, tail>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
 		}
+		tail_timer.reset();
 		if (side) {
 			GSR_HIP_CHECK(hipEventRecord(side->done, side->stream));
 			side->recorded = true;
@@ -1061,7 +1094,7 @@ extern "C" int gsr_deferred_reflection_backward_accum(const float* normal_view, 
                                                 float* scratch, size_t scratch_floats, int accumulate, void* stream_) {
 	return gsr_deferred_reflection_backward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
 	                                           g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate, 0, nullptr,
-	                                           stream_);
+	                                           nullptr, stream_);
 }
 
 extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,

@@ -365,6 +365,9 @@ __device__ __forceinline__ float div_nr(float a, float b) {
 // [x0,x1]x[y0,y1] (already inflated by half a pixel by the caller): the minimum of a convex quadratic over a box is
 // attained at the centre if it lies inside, otherwise on one of the four edges.  The vote runs once per (wave, list
 // entry) with one entry per lane, so its ~40 instructions cost less than one per entry.
+#ifndef GSR_CULL_RCP
+#define GSR_CULL_RCP 1     // 1-ulp v_rcp instead of two IEEE divisions in the footprint vote: tile forward 0.503 -> 0.496 ms at C3
+#endif
 __device__ __forceinline__ bool cull_hit(const float4 c0, const float4 c1, float x0, float x1, float y0, float y1) {
 	if (c1.w == -2.0f) return false;
 	const float a = c0.z, b = c0.w, c = c1.x;
@@ -373,7 +376,11 @@ __device__ __forceinline__ bool cull_hit(const float4 c0, const float4 c1, float
 	bool hit = ex >= x0 && ex <= x1 && ey >= y0 && ey <= y1;
 	if (!hit) {
 		float best = __int_as_float(0x7f800000);
+#if GSR_CULL_RCP
+		const float boc = b * __builtin_amdgcn_rcpf(c), boa = b * __builtin_amdgcn_rcpf(a);   // 1-ulp reciprocals: the point they place on an edge
+#else                                                                                         // moves by 1e-7 of its offset, the form there by its square
 		const float boc = b / c, boa = b / a;
+#endif
 #pragma unroll
 		for (int e = 0; e < 2; e++) {
 			const float dx = (e ? x1 : x0) - ex;

@@ -95,6 +95,9 @@ def _ray_block(view):
 # ------------------------------------------------------------------------------------------- fused pixel passes
 # True: sorted-footprint path of the reflection backward (~44 bytes of scratch per pixel); False: float atomics
 REFLECTION_BACKWARD_BINNED = True
+# True: the forward writes the sort keys of the backward's footprint records (4 bytes per pixel), so that the backward's sort runs beside
+# its pixel kernel instead of after it; False: the backward's pixel kernel writes them (what a plain C-ABI caller gets)
+REFLECTION_FORWARD_KEYS = True
 
 
 class _DeferredReflection(torch.autograd.Function):
@@ -110,11 +113,17 @@ class _DeferredReflection(torch.autograd.Function):
         normal_world = torch.empty_like(nv)
         # texel-interleaved copy of the cubemap for the pixel kernels (one 16-byte gather per bilinear corner); the backward reuses it
         rgba = torch.empty(6 * cm.shape[2] * cm.shape[3] * 4, dtype=torch.float32, device=cm.device)
+        # sort keys of the backward's footprint records (they depend on forward data only): written here when a backward can follow, so
+        # that its sort does not have to wait for its pixel kernel
+        keys = None
+        if REFLECTION_BACKWARD_BINNED and REFLECTION_FORWARD_KEYS and any(ctx.needs_input_grad[:5]):
+            keys = torch.empty(H * W, dtype=torch.int32, device=cm.device)
         with torch.cuda.device(nv.device):
             check(lib.gsr_deferred_reflection_forward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(final),
-                                                         ptr(refl_color), ptr(normal_world), ptr(rgba), stream_ptr(nv.device)),
+                                                         ptr(refl_color), ptr(normal_world), ptr(rgba), ptr(keys), stream_ptr(nv.device)),
                   "gsr_deferred_reflection_forward")
         ctx.save_for_backward(nv, bc, rs, cm, fv, cam, rgba)
+        ctx.sort_keys = keys
         ctx.sink = sink
         ctx.set_materialize_grads(False)   # outputs nobody differentiates arrive as None instead of zero-filled [3,H,W] tensors
         return final, refl_color, normal_world
@@ -149,9 +158,10 @@ class _DeferredReflection(torch.autograd.Function):
             check(lib.gsr_deferred_reflection_backward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
                                                           ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
                                                           ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
-                                                          int(async_tail), ptr(rgba), stream_ptr(nv.device)), "gsr_deferred_reflection_backward")
+                                                          int(async_tail), ptr(rgba), ptr(ctx.sort_keys), stream_ptr(nv.device)),
+                  "gsr_deferred_reflection_backward")
         if async_tail:
-            _gsr.side_hold(scratch, g_cm, g_fail)     # read / written on the side stream until side_join()
+            _gsr.side_hold(scratch, g_cm, g_fail, ctx.sort_keys)     # read / written on the side stream until side_join()
         return g_nv, g_base, g_s, (None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None, None
 
 

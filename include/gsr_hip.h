@@ -211,25 +211,32 @@ int gsr_deferred_reflection_backward_accum(const float* normal_view, const float
                                      int accumulate, void* stream);
 /* Extension: async_tail != 0 (sorted path only) enqueues the part of the backward that produces g_cubemap / g_fail — sort of
  * the footprint records, run combine, unpack; nothing else in a training step depends on it before the optimizer — on a
- * low-priority side stream owned by the library (one per device) that forks from `stream` after the pixel kernel, so that
+ * side stream owned by the library (one per device, highest priority) that forks from `stream` after the pixel kernel, so that
  * it runs beside whatever the caller enqueues next on `stream` (the rasterizer backward).  g_normal_view / g_base /
  * g_strength are complete in `stream` order as always.  g_cubemap, g_fail and scratch must stay untouched and alive until
  * gsr_side_join(s) has been called: it makes stream s wait (device-side, no host block) for all side work enqueued so far
- * on the current device.  Successive tails are ordered among themselves (accumulate over a batch of views works). */
+ * on the current device.  Successive tails are ordered among themselves (accumulate over a batch of views works).
+ * sort_keys (NULL, or the width*height keys gsr_deferred_reflection_forward_ex wrote for the SAME inputs): the sort of the
+ * footprint records then depends on nothing this call computes; with async_tail it forks before the pixel kernel and runs
+ * beside it, and only the run combine waits for the records.  The keys must stay alive and untouched like scratch. */
 int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
                                         const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
                                         int width, int height, const float* g_final, const float* g_refl_color,
                                         const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
                                         float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
-                                        int accumulate, int async_tail, const float* cubemap_rgba, void* stream);
+                                        int accumulate, int async_tail, const float* cubemap_rgba, const uint32_t* sort_keys,
+                                        void* stream);
 int gsr_side_join(void* stream);
 /* Extension: cubemap_rgba (NULL, or 6*L*L*4 floats, 16-byte aligned) receives a texel-interleaved copy [6][L][L][r,g,b,0] of
  * the cubemap, made by the call, from which the pixel kernel gathers each bilinear corner with one 16-byte load instead of
- * three 4-byte ones; hand the same buffer to gsr_deferred_reflection_backward_ex (cubemap_rgba) of the same cubemap, or NULL. */
+ * three 4-byte ones; hand the same buffer to gsr_deferred_reflection_backward_ex (cubemap_rgba) of the same cubemap, or NULL.
+ * sort_keys (NULL, or width*height uint32): receives, per pixel, the sort key of the record the sorted-footprint backward will
+ * make for it — the texel id of the upper-left corner of its bilinear footprint, or 6*L*L when the footprint leaves its cube
+ * face or the reflection vector is zero; it depends on forward data only (see gsr_deferred_reflection_backward_ex). */
 int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
                                        const float* cam, const float* cubemap, const float* fail_value, uint32_t L, int width,
                                        int height, float* out_final, float* out_refl_color, float* out_normal_world,
-                                       float* cubemap_rgba, void* stream);
+                                       float* cubemap_rgba, uint32_t* sort_keys, void* stream);
 /* Shading normal alone: out = normalize(normal_view rotated to world space) with the reference's +1e-6
  * (gaussian_renderer/__init__.py:148,178-179), for the initial stage where render() skips the reflection chain but still
  * returns rend_normal; `cam` as above (only its first nine floats are read).  The backward writes g_normal_view fully. */

@@ -172,8 +172,9 @@ def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
     f_r, c_r, n_r = _reference_chain(nv_r, base_r, s_r, tex_r, fail_r, cam, W, H)
     ((f_r * wf.double()).sum() + (c_r * wc.double()).sum() + (n_r * wn.double()).sum()).backward()
     grads = {}
-    for binned in (True, False):
-        monkeypatch.setattr(gaussian_renderer, "REFLECTION_BACKWARD_BINNED", binned)
+    for binned in (True, "keys written by the backward", False):
+        monkeypatch.setattr(gaussian_renderer, "REFLECTION_BACKWARD_BINNED", bool(binned))
+        monkeypatch.setattr(gaussian_renderer, "REFLECTION_FORWARD_KEYS", binned is True)
         cu = lambda x: x.float().cuda().clone().requires_grad_(True)
         nv_h, base_h, s_h, tex_h, fail_h = cu(nv), cu(base), cu(strength), cu(tex), cu(fail)
         env = Env()
@@ -186,6 +187,9 @@ def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
         # (the bilinear weights are differences of texel coordinates ~L/2: their float32 resolution grows with L)
         assert rel_maxnorm(grads[binned][3], tex_r.grad.numpy()) <= (1e-4 if L <= 256 else 3e-4)
         assert rel_maxnorm(grads[binned][1], base_r.grad.numpy()) <= 1e-5
+    # sort keys from the forward kernel or from the backward's pixel kernel: the same stable sort of the same keys, bit for bit
+    for a, b in zip(grads[True], grads["keys written by the backward"]):
+        assert np.array_equal(a, b) or rel_maxnorm(a, b) <= 1e-6     # (rim pixels add with float atomics: arrival order)
     for a, b in zip(grads[True][:3], grads[False][:3]):
         assert rel_maxnorm(a, b) <= 1e-4   # same formulas in two kernels; contraction order differs and 1/|n| amplifies it
     # the two kernels contract the direction arithmetic differently: texel coordinates an ulp apart, times L
@@ -238,13 +242,16 @@ def test_reflection_grad_sink_routes_cubemap_gradients():
         run({"cubemap": acc["cubemap"]}, accumulate=True)
 
 
-def test_reflection_async_tail_joined_before_the_sink_is_read():
+@pytest.mark.parametrize("forward_keys", [True, False])
+def test_reflection_async_tail_joined_before_the_sink_is_read(forward_keys, monkeypatch):
     """Extension: async_tail=True puts the cubemap-gradient part of the backward on the library's side stream.  The per-pixel
     gradients autograd receives are unaffected; the sink is complete after _gsr.side_join() — overwrite and accumulate over
     two backwards, a busy main stream in between — and FlatGrads.all_reduce() joins by itself."""
     import _gsr
+    import gaussian_renderer
     from gaussian_renderer import deferred_reflection
     from gsr_dist import FlatGrads
+    monkeypatch.setattr(gaussian_renderer, "REFLECTION_FORWARD_KEYS", forward_keys)    # sort beside the pixel kernel / after it (small shape)
     W, H, L = 640, 360, 32
     cam = S.look_at_camera(W, H, eye=(1.0, -0.5, -4.0))
     ct = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cam.items() if isinstance(v, np.ndarray)}
