@@ -62,6 +62,8 @@ static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
 static int g_opt_dev = 0;
 int option_dev() { return g_opt_dev; }
+static int g_opt_mailbox = 1;
+static int option_mailbox() { return g_opt_mailbox; }
 static int g_opt_sort_driver = GSR_ONESWEEP_DRIVER;
 int option_sort_driver() { return GSR_ONESWEEP_DRIVER && g_opt_sort_driver; }
 
@@ -220,7 +222,8 @@ BinningState carve_binning(void* buf, size_t R, size_t tiles, size_t sort_bytes,
 // from 0.044 to 0.114 ms at C3 and from 0.12 to 0.38 ms at C5 to save an 8-us dispatch.  The depth keys' low digits are spread over 256 bins.)
 #define STATS_BLOCK 1024
 __global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, const float* __restrict__ depths, const uint32_t* __restrict__ tiles_touched,
-                                                                      uint32_t* __restrict__ depth_counts, int* __restrict__ flags) {
+                                                                      uint32_t* __restrict__ depth_counts, int* __restrict__ flags, int* __restrict__ mailbox,
+                                                                      uint32_t seq) {
 	__shared__ uint32_t s_hist[DEPTH_KEY_PLACES * 256u];
 	__shared__ unsigned long long s_sum[STATS_BLOCK / 64];
 	const uint32_t t = threadIdx.x;
@@ -253,6 +256,17 @@ __global__ void __launch_bounds__(STATS_BLOCK) gaussian_stats_kernel(int P, cons
 	if (t == 0u) {
 		for (uint32_t w = 1; w < STATS_BLOCK / 64; w++) sum += s_sum[w];
 		if (sum != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(flags + 2), sum);
+		// mailbox (pinned, host-coherent): the LAST workgroup to get here hands num_rendered to the waiting host thread itself — no copy
+		// packet and no barrier between this kernel and the depth sort behind it (4 us of copy + 6 us of gap on the forward's critical path)
+		if (mailbox != nullptr) {
+			const uint32_t ticket = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(flags + 1), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+			if (ticket == gridDim.x - 1u) {
+				const unsigned long long total = __hip_atomic_load(reinterpret_cast<unsigned long long*>(flags + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(mailbox + 2, (int)(uint32_t)(total & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(mailbox + 3, (int)(uint32_t)(total >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<uint32_t*>(mailbox + 4), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
 	}
 	if (depth_counts != nullptr) {
 		const uint32_t h = s_hist[t];
@@ -460,7 +474,9 @@ __global__ void __launch_bounds__(256) rebuild_keys_kernel(int L, const uint32_t
 // 4-byte cudaMemcpy on the default stream, rasterizer_impl.cu:286).  Keyed by the current device: an event created on one
 // device must not be recorded on another device's stream.
 struct Readback {
-	int* word = nullptr;
+	int* word = nullptr;       // host address of the pinned words: [0] trap flag, [2,3] num_rendered, [4] sequence number of the mailbox write
+	int* dev_word = nullptr;   // the same memory as the device sees it
+	uint32_t seq = 0;
 	hipEvent_t done = nullptr;
 };
 static Readback* readback_slot() {
@@ -468,7 +484,11 @@ static Readback* readback_slot() {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
 	Readback& r = slots[dev];
-	if (!r.word && hipHostMalloc((void**)&r.word, 64, hipHostMallocDefault) != hipSuccess) { r.word = nullptr; return nullptr; }
+	if (!r.word) {
+		if (hipHostMalloc((void**)&r.word, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { r.word = nullptr; return nullptr; }
+		memset(r.word, 0, 64);
+		if (hipHostGetDevicePointer((void**)&r.dev_word, r.word, 0) != hipSuccess) r.dev_word = nullptr;   // (then the copy path below is used)
+	}
 	if (!r.done && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) { r.done = nullptr; return nullptr; }
 	return &r;
 }
@@ -478,6 +498,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	Readback* rb = readback_slot();
 	if (!rb) { set_error("pinned word / event for the num_rendered readback could not be created"); return GSR_E_HIP; }
 	int* host = rb->word;
+	int* mailbox = nullptr;
+	uint32_t seq = 0;
 	const bool own_depth_sort = option_sort_driver() && (size_t)P <= SORT_MAX_ITEMS;
 	{
 		StageTimer st_(GSR_STAGE_SCAN, stream);
@@ -486,11 +508,13 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		// order from the second scan below, and gsr_debug_fetch("point_offsets") computes them on demand)
 		// one dispatch: the 64-bit sum and the depth keys' digit counts (gaussian_stats_kernel)
 		const unsigned blocks = (unsigned)std::min<size_t>(512, ((size_t)P + 4 * STATS_BLOCK - 1) / (4 * STATS_BLOCK));
+		// the trap flag flags[0] is only ever set, and cleared, with `prefiltered`: that (debugging) mode copies the four words back instead
+		mailbox = (!prefiltered && rb->dev_word != nullptr && option_mailbox()) ? rb->dev_word : nullptr;
+		seq = ++rb->seq;
 		gaussian_stats_kernel<<<blocks, STATS_BLOCK, 0, stream>>>(P, geom.depths, geom.tiles_touched,
-		                                                          own_depth_sort ? reinterpret_cast<uint32_t*>(geom.depth_sort_temp) : nullptr, geom.flags);
+		                                                          own_depth_sort ? reinterpret_cast<uint32_t*>(geom.depth_sort_temp) : nullptr, geom.flags, mailbox, seq);
 		GSR_LAUNCH_CHECK(debug, stream);
-		// flags[2,3] num_rendered; flags[0] (the trap flag) is only ever set, and cleared, with `prefiltered`
-		GSR_HIP_CHECK(hipMemcpyAsync(host, geom.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+		if (!mailbox) GSR_HIP_CHECK(hipMemcpyAsync(host, geom.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
 	}
 	// the host waits on THIS point only, not on the level-1 work enqueued behind it
 	hipEvent_t readback_done = rb->done;
@@ -509,7 +533,21 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
 	}
-	GSR_HIP_CHECK(hipEventSynchronize(readback_done));
+	if (mailbox) {
+		// spin on the sequence number the last workgroup of gaussian_stats_kernel stores; the event (recorded right behind that kernel) is the
+		// way out if the store is not seen while the kernel runs — once the kernel has completed its writes are visible in any case
+		volatile uint32_t* box = reinterpret_cast<volatile uint32_t*>(host);
+		while (box[4] != seq) {
+			if (hipEventQuery(readback_done) != hipErrorNotReady) break;
+		}
+		if (box[4] != seq) {
+			GSR_HIP_CHECK(hipEventSynchronize(readback_done));
+			if (box[4] != seq) { set_error("num_rendered mailbox was not written"); return GSR_E_HIP; }
+		}
+		__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	} else {
+		GSR_HIP_CHECK(hipEventSynchronize(readback_done));
+	}
 	unsigned long long total64;
 	memcpy(&total64, host + 2, sizeof(total64));
 	if (prefiltered && host[0] != 0) { set_error("Point is filtered although prefiltered is set. This shouldn't happen!"); return GSR_E_PREFILTERED; }
@@ -606,6 +644,7 @@ extern "C" int gsr_version(void) { return 100; }
 extern "C" int gsr_set_option(const char* name, int value) {
 	if (std::string(name) == "cull") { g_opt_cull = value ? 1 : 0; return 0; }
 	if (std::string(name) == "dev") { g_opt_dev = value; return 0; }
+	if (std::string(name) == "mailbox") { g_opt_mailbox = value ? 1 : 0; return 0; }   // 0: num_rendered comes back through a copy + event (round 2)
 	if (std::string(name) == "sort_driver") { g_opt_sort_driver = value ? 1 : 0; return 0; }   // 0: public rocprim::radix_sort_pairs everywhere
 	set_error("gsr_set_option: unknown option '%s'", name);
 	return GSR_E_INVALID;

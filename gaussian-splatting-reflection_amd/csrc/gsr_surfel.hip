@@ -244,7 +244,7 @@ surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, c
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
 	sort_clear_region(g.emit_state, g.emit_state_bytes, (size_t)idx, (size_t)gridDim.x * 256u);   // look-back state of emit_tiles_kernel's scan
-	if (idx == 0) { g.flags[2] = 0; g.flags[3] = 0; }   // num_rendered (64 bits): accumulated by gaussian_stats_kernel
+	if (idx == 0) { g.flags[1] = 0; g.flags[2] = 0; g.flags[3] = 0; }   // [1] workgroup tickets, [2,3] num_rendered (64 bits) of gaussian_stats_kernel
 	__shared__ float4 s_out[4][S_REC_F4 * 65];
 	const int lane = threadIdx.x & 63;
 	float4* so = s_out[threadIdx.x >> 6];

@@ -452,3 +452,29 @@ def test_normal_view_tap_equals_the_slice():
                   antialiasing=False)).set_output_taps(("normal_view",))
     with pytest.raises(NotImplementedError):
         GaussianRasterizer(settings).set_output_taps(("depth",))
+
+
+@pytest.mark.parametrize("variant", ["S", "G"])
+def test_num_rendered_mailbox_equals_the_copy_path(variant):
+    """num_rendered reaches the host through a pinned mailbox word written by the last workgroup of the statistics kernel
+    (default) or through the round-2 copy + event (gsr_set_option("mailbox", 0)): same count, same outputs, call after call
+    (the sequence number distinguishes consecutive forwards, also across different scenes)."""
+    import _gsr
+    outs = {}
+    try:
+        for mode in (1, 0, 1):
+            _gsr.set_option("mailbox", mode)
+            for seed, P in ((41, 3000), (42, 5000), (41, 3000)):
+                kw, _, _ = scene_kwargs(variant, P, 200, 120, seed, -2.8, 3, (0, 0, 0))
+                hip = HipSurfel(kw) if variant == "S" else HipGauss(kw, antialiasing=False)
+                o = hip.out()
+                key = (seed, P)
+                if key in outs:
+                    assert o["num_rendered"] == outs[key]["num_rendered"]
+                    assert np.array_equal(o["color"], outs[key]["color"]) and np.array_equal(o["radii"], outs[key]["radii"])
+                else:
+                    outs[key] = o
+                assert o["num_rendered"] == int(hip.state("tiles_touched").astype(np.int64).sum())
+    finally:
+        _gsr.set_option("mailbox", 1)
+    assert outs[(41, 3000)]["num_rendered"] != outs[(42, 5000)]["num_rendered"]
