@@ -37,7 +37,8 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
+N_SIMDS = 256 * 4
+VALU_PEAK_WAVE_INSTS_PER_S = N_SIMDS * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 HBM_MEASURED_GBS = 6290.0    # same guide: the float4-copy ceiling measured on this part (SURVEY.md §8d asks for both)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 PMC_FILE_C5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_summary.json")
@@ -255,7 +256,21 @@ def main():
     stages = _gsr.profile_collect()
     _gsr.profile_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    R_headline = info["R"]      # (later objects render other views: their instance counts must not leak into the headline's byte counts)
     allreduce_ms = float(np.median([a.elapsed_time(b) for a, b in ar_marks])) if ar_marks else 0.0
+    # the dominant kernel on its own: a few more steps with the reflection tail on the step's stream (nothing runs beside the tile backward)
+    alone_ms = None
+    if not args.sync_reflection_tail:
+        args.sync_reflection_tail = True
+        _gsr.profile_enable(True)
+        for _ in range(5):
+            step()
+        sync_all()
+        a = _gsr.profile_collect()
+        _gsr.profile_enable(False)
+        args.sync_reflection_tail = False
+        if a["render_bwd"][1] > 0:
+            alone_ms = a["render_bwd"][0] / a["render_bwd"][1]
 
     # N > 1, labelled extra: the same steps with the all-reduce of step k (RCCL, its own stream) overlapped with step k+1, which
     # renders into a second buffer.  Nothing consumes the reduced gradients in that loop — a training step cannot do this
@@ -351,7 +366,7 @@ def main():
     value = views_total * args.steps / dt
 
     if rank == 0:
-        R = info["R"]
+        R = R_headline
         HW = W * H
         nv = len(views)
         bwd_ms, bwd_n = stages["render_bwd"]
@@ -368,6 +383,10 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_measured_ceiling": round(achieved / HBM_MEASURED_GBS, 4),
                 "measured_ceiling": HBM_MEASURED_GBS, "traffic": pmc.get("traffic"),
                 "traffic_source": pmc.get("source"), "avg_launch_ms": round(launch_s * 1e3, 4), "algorithmic_bytes_per_launch": bytes_bwd}
+        if alone_ms:
+            # the same kernel without the reflection's run combine beside it (extra steps with the tail on the step's stream, outside the timed region)
+            roof["avg_launch_ms_alone"] = round(alone_ms, 4)
+            roof["frac_alone"] = round(bytes_bwd / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if pmc.get("insts_valu"):
             rate = pmc["insts_valu"] / launch_s
             roof["bound2"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 1),
@@ -376,6 +395,15 @@ def main():
                               "what": "SQ_INSTS_VALU of the committed PMC pass / the launch time measured in this run, against one wave64 VALU "
                                       "instruction per SIMD per 2 cycles; the kernel's mix (packed fp32, SGPR operands, DPP: ~4 cycles each, "
                                       "tests/microbench/inst_cost.hip) puts its own issue bound at ~1.0 of the measured time (DESIGN.md)"}
+            mix = isa_mix("surfel_render_bwd_rows_kernel")
+            if mix:
+                # issue bound of THIS kernel's instruction mix: its VALU count (PMC) x the average issue cost of the hot loop's static mix
+                # (tests/isa_mix.py: compiler assembly of this build, priced with the measured per-class costs) / the chip's 1024 SIMDs
+                bound_ms = pmc["insts_valu"] * mix["avg_ns_per_valu"] * 1e-6 / N_SIMDS
+                roof["bound2"]["issue_bound_of_this_mix"] = {
+                    "avg_ns_per_valu_instruction": mix["avg_ns_per_valu"], "static_mix_of_the_hot_loop": mix["mix"], "bound_ms": round(bound_ms, 4),
+                    "frac": round(bound_ms / (launch_s * 1e3), 4), "frac_alone": round(bound_ms / alone_ms, 4) if alone_ms else None,
+                    "source": "profiles/r03_isa_mix.json (tests/isa_mix.py, same build digest) x SQ_INSTS_VALU of the PMC pass"}
         out = {
             "metric": "train_step_views_per_s (fwd+bwd, 1e6 Gaussians @1080p, surfel rasterizer + reflection path)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -693,6 +721,18 @@ def c5_object(S, dev, steps=5):
     torch.cuda.empty_cache()
     return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd", "num_rendered": R[0],
             "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps, "stage_ms_per_step": stage, "kernel_sum_ms": round(sum(stage.values()), 4), "roofline": kernels}
+
+
+def isa_mix(kernel):
+    """Static instruction mix of `kernel`'s hot loop (profiles/r03_isa_mix.json, tests/isa_mix.py), quoted only for the build it was taken on."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))
+        built = open(DIGEST_FILE).read().strip()
+    except (OSError, ValueError):
+        return None
+    if j.get("_config", {}).get("digest") != built:
+        return None
+    return j.get(kernel)
 
 
 def pmc_summary(kernel, P, W, H, PMC_FILE=PMC_FILE):
