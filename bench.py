@@ -122,6 +122,9 @@ def main():
                     help="keep the cubemap-gradient tail of the reflection backward on the main stream (default: side stream, joined by the all-reduce)")
     ap.add_argument("--no-overlap-extra", action="store_true", help="N > 1: skip the extra loop that overlaps the all-reduce with the next step")
     ap.add_argument("--only-c5", action="store_true", help="run only the C5 object (5e6 Gaussians, variant G) and print it: the command the C5 rocprofv3 passes wrap")
+    ap.add_argument("--view-streams", type=int, default=1,
+                    help="views of a rank's batch alternate over this many torch streams: the binning chain of view i+1 (launch-latency-bound) runs beside "
+                         "the tile kernels of view i (VALU-bound); the backwards stay ordered (they add into one gradient buffer)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in object (reference entry points with plain autograd)")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1, full_train_step: reduce-scatter -> Adam on this rank's 1/N of the flat buffer -> all-gather instead of all-reduce -> full Adam")
@@ -211,13 +214,37 @@ def main():
     # FlatGrads.all_reduce() makes the step's stream wait for it, so it is inside the timed region.
     ar_marks = []      # (start, end) event pairs around the all-reduce; filled only in the instrumented pass
 
+    vstreams = [torch.cuda.Stream(device=dev) for _ in range(args.view_streams)] if args.view_streams > 1 else []
+
     def step_into(buf, reduce, timed=False, batch=None):
         sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
-        for i, view in enumerate(views if batch is None else batch):
-            view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
-            means2D.grad = None
-            final, allmap = render(view, rsink, i > 0)
-            torch.autograd.backward([final, allmap], [g_final, g_allmap])
+        vs = views if batch is None else batch
+        if vstreams and len(vs) > 1:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            done = []
+            for i, view in enumerate(vs):
+                st = vstreams[i % len(vstreams)]
+                if i < len(vstreams):
+                    st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
+                    means2D.grad = None
+                    final, allmap = render(view, rsink, i > 0)
+                    if done:
+                        st.wait_event(done[-1])      # the backwards add into ONE buffer: view i's may not start before view i-1's is over
+                    torch.autograd.backward([final, allmap], [g_final, g_allmap])
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
+            main.wait_event(done[-1])
+        else:
+            for i, view in enumerate(vs):
+                view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
+                means2D.grad = None
+                final, allmap = render(view, rsink, i > 0)
+                torch.autograd.backward([final, allmap], [g_final, g_allmap])
         if not timed:
             return reduce(buf)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
