@@ -691,7 +691,9 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 			F3 grgb = f3(0.f, 0.f, 0.f);
 #pragma unroll
 			for (int k = 0; k < 16; k++) w[k] = 0.f;
-			if (visible) {
+			// (a Gaussian that blended into no pixel has a zero colour gradient: its SH row of the gradient and the view-direction term
+			// are zeros whatever the coefficients are, so their 192 bytes are not read)
+			if (visible && (a0.x != 0.f || a0.y != 0.f || a0.z != 0.f)) {
 				ShRow s;
 				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
