@@ -243,7 +243,11 @@ __device__ __forceinline__ void wave_store_rows(float* lds, const float* v, floa
 		const int e = lane + 64 * j, r = e / N, k = e - r * N;
 		if (r < nrows) {
 			const float x = lds[k * 65 + r];
-			out[e] = ACC ? out[e] + x : x;
+			if (ACC) {
+				if (x != 0.f) out[e] += x;      // (adding zero is a no-op: the rows of Gaussians this view did not touch are neither read nor written)
+			} else {
+				out[e] = x;
+			}
 		}
 	}
 	wave_lds_sync();
@@ -261,8 +265,10 @@ __device__ __forceinline__ void wave_store_rows4(float4* lds, const float4* v, f
 			const float4 x = lds[k * 65 + r];
 			float4* o = out + (size_t)r * pitch + col0 + k;
 			if (ACC) {
-				const float4 y = *o;
-				*o = make_float4(y.x + x.x, y.y + x.y, y.z + x.z, y.w + x.w);
+				if (x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f) {
+					const float4 y = *o;
+					*o = make_float4(y.x + x.x, y.y + x.y, y.z + x.z, y.w + x.w);
+				}
 			} else {
 				*o = x;
 			}

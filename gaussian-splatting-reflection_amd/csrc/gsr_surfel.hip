@@ -918,7 +918,10 @@ __device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, con
 // Writes every output element (zeros for culled surfels).
 // ACC: the parameter gradients (mean3D, sh, opacity, scale, rotation, refl strength) are ADDED to the output tensors instead
 // of written: several views accumulate into one gradient buffer on the device (gsr_surfel_backward_accum).
-template <bool ACC> __device__ __forceinline__ void put(float* p, float v) { *p = ACC ? *p + v : v; }
+template <bool ACC> __device__ __forceinline__ void put(float* p, float v) {
+	if (ACC) { if (v != 0.f) *p += v; }     // (a view adds nothing to the Gaussians it did not touch: no read, no write)
+	else *p = v;
+}
 template <bool ACC>
 __global__ void __launch_bounds__(256)
 surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
@@ -1101,8 +1104,10 @@ surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ mean
 		put<ACC>(dL_dscale + 2 * idx, dscale[0]); put<ACC>(dL_dscale + 2 * idx + 1, dscale[1]);
 		float4* rq = reinterpret_cast<float4*>(dL_drot) + idx;
 		if (ACC) {
-			const float4 r0 = *rq;
-			*rq = make_float4(r0.x + drot[0], r0.y + drot[1], r0.z + drot[2], r0.w + drot[3]);
+			if (drot[0] != 0.f || drot[1] != 0.f || drot[2] != 0.f || drot[3] != 0.f) {
+				const float4 r0 = *rq;
+				*rq = make_float4(r0.x + drot[0], r0.y + drot[1], r0.z + drot[2], r0.w + drot[3]);
+			}
 		} else {
 			*rq = make_float4(drot[0], drot[1], drot[2], drot[3]);
 		}
