@@ -516,9 +516,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		GSR_LAUNCH_CHECK(debug, stream);
 		if (!mailbox) GSR_HIP_CHECK(hipMemcpyAsync(host, geom.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
 	}
-	// the host waits on THIS point only, not on the level-1 work enqueued behind it
+	// the host waits on THIS point only, not on the level-1 work enqueued behind it.  (With the mailbox no event is recorded: an event record
+	// is a 5-us bubble between the statistics kernel and the depth sort; the fallback of the spin below is the stream itself.)
 	hipEvent_t readback_done = rb->done;
-	GSR_HIP_CHECK(hipEventRecord(readback_done, stream));
+	if (!mailbox) GSR_HIP_CHECK(hipEventRecord(readback_done, stream));
 	{
 		// level 1 (independent of num_rendered, so it runs while the host waits for the read-back): depth order of the
 		// Gaussians (31 key bits: depths are positive floats, their bit patterns order like the values); the scan of the
@@ -534,14 +535,16 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
 	}
 	if (mailbox) {
-		// spin on the sequence number the last workgroup of gaussian_stats_kernel stores; the event (recorded right behind that kernel) is the
-		// way out if the store is not seen while the kernel runs — once the kernel has completed its writes are visible in any case
+		// spin on the sequence number the last workgroup of gaussian_stats_kernel stores; the way out, should the store not be seen while
+		// the kernel runs, is the stream running dry (the depth sort behind it, ~0.07 ms later): once the kernel has completed its writes are
+		// visible in any case
 		volatile uint32_t* box = reinterpret_cast<volatile uint32_t*>(host);
+		unsigned spins = 0;
 		while (box[4] != seq) {
-			if (hipEventQuery(readback_done) != hipErrorNotReady) break;
+			if ((++spins & 63u) == 0u && hipStreamQuery(stream) != hipErrorNotReady) break;
 		}
 		if (box[4] != seq) {
-			GSR_HIP_CHECK(hipEventSynchronize(readback_done));
+			GSR_HIP_CHECK(hipStreamSynchronize(stream));
 			if (box[4] != seq) { set_error("num_rendered mailbox was not written"); return GSR_E_HIP; }
 		}
 		__atomic_thread_fence(__ATOMIC_ACQUIRE);
