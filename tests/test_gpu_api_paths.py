@@ -478,3 +478,15 @@ def test_num_rendered_mailbox_equals_the_copy_path(variant):
     finally:
         _gsr.set_option("mailbox", 1)
     assert outs[(41, 3000)]["num_rendered"] != outs[(42, 5000)]["num_rendered"]
+
+
+def test_num_rendered_beyond_int32_is_refused():
+    """40 000 splats that each cover (nearly) all 65 536 tiles of a 4096 x 4096 image: the instance count (~2.6e9) does not fit the int the
+    API returns.  The reference's 32-bit InclusiveSum wraps silently (rasterizer_impl.cu:282) and then allocates and sorts garbage;
+    here the count is reduced in 64 bits and the call is refused before the binning workspace is sized."""
+    kw, _, _ = scene_kwargs("G", 40_000, 4096, 4096, 12, 0.0, 0, (0, 0, 0))
+    with pytest.raises(RuntimeError, match="does not fit"):
+        HipGauss(kw, requires_grad=False)
+    # the library is usable afterwards
+    kw2, _, _ = scene_kwargs("G", 2000, 160, 96, 13, -2.5, 0, (0, 0, 0))
+    assert (HipGauss(kw2, requires_grad=False).out()["radii"] > 0).any()
