@@ -485,9 +485,14 @@ static Readback* readback_slot() {
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
 	Readback& r = slots[dev];
 	if (!r.word) {
-		if (hipHostMalloc((void**)&r.word, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { r.word = nullptr; return nullptr; }
+		if (hipHostMalloc((void**)&r.word, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+			if (hipHostGetDevicePointer((void**)&r.dev_word, r.word, 0) != hipSuccess) r.dev_word = nullptr;   // (then the copy path below is used)
+		} else {
+			(void)hipGetLastError();
+			r.dev_word = nullptr;      // no coherent mapping on this system: plain pinned memory and the copy + event path
+			if (hipHostMalloc((void**)&r.word, 64, hipHostMallocDefault) != hipSuccess) { r.word = nullptr; return nullptr; }
+		}
 		memset(r.word, 0, 64);
-		if (hipHostGetDevicePointer((void**)&r.dev_word, r.word, 0) != hipSuccess) r.dev_word = nullptr;   // (then the copy path below is used)
 	}
 	if (!r.done && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) { r.done = nullptr; return nullptr; }
 	return &r;
