@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s mea
 N_SIMDS = 256 * 4
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMDS * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 HBM_MEASURED_GBS = 6290.0    # same guide: the float4-copy ceiling measured on this part (SURVEY.md §8d asks for both)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-PMC_FILE_C5 = os.path.join(ROOT, "profiles", "r03_c5_pmc_summary.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_FILE_C5 = os.path.join(ROOT, "profiles", "r04_c5_pmc_summary.json")
 DIGEST_FILE = os.path.join(PKG, "csrc", "_obj", "digest.txt")      # written by csrc/build.py: sha256 over every kernel source + flags
 
 
@@ -49,9 +49,9 @@ class Scene:
     """Parameters of the synthetic scene as leaf tensors whose .grad are views into ONE flat buffer
     (gsr_dist.FlatGrads: the all-reduce payload, 59 floats per Gaussian + cubemap texels + fail value)."""
 
-    def __init__(self, S, P, mu, L, device, seed):
+    def __init__(self, S, P, mu, L, device, seed, ball=False):
         from gsr_dist import FlatGrads
-        sc = S.make_scene(P, "S", seed=seed, mu=mu)
+        sc = S.make_scene(P, "S", seed=seed, mu=mu, ball=ball)
         tex, fail = S.make_cubemap(L, 3, seed)
         names = ["means3D", "shs", "opacities", "scales", "rotations", "refl_strengths"]
         src = {k: torch.from_numpy(sc[k]) for k in names}
@@ -61,12 +61,14 @@ class Scene:
         self.grads = FlatGrads(self.p)
         self.mask = torch.from_numpy(sc["env_scope_mask"]).to(device)
         self.P = P
+        self.env = EnvMap(self.p["cubemap"], self.p["fail"])
+        self.means2D = torch.zeros(P, 3, device=device, requires_grad=True)
 
     def release(self):
         """Drop parameters and the flat gradient buffer (the end-to-end leg re-creates them inside its own flat store)."""
         for p in self.p.values():
             p.grad = None
-        self.p, self.grads = {}, None
+        self.p, self.grads, self.env, self.means2D = {}, None, None, None
 
 
 class EnvMap:
@@ -77,9 +79,9 @@ class EnvMap:
 class View:
     """One camera of the batch with its own rasterizer instance (the gradient sink is per rasterizer)."""
 
-    def __init__(self, S, index, W, H, dev):
+    def __init__(self, S, index, W, H, dev, cam=None):
         from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-        cam = S.yaw_camera(W, H, 3.0 * index)     # view v of the batch looks 3 v degrees to the side
+        cam = cam or S.yaw_camera(W, H, 3.0 * index)     # view v of the batch looks 3 v degrees to the side
         self.ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
         self.HWK = (H, W, cam["K"])
         settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
@@ -87,8 +89,8 @@ class View:
                                                  projmatrix=self.ct["projmatrix"], sh_degree=3, campos=self.ct["campos"], prefiltered=False,
                                                  debug=False)
         self.rasterizer = GaussianRasterizer(settings)
-        # allmap[2:5] as an output tap: the reflection pass's normal gradient reaches the tile backward as its own pointer instead of
-        # through autograd's zero-fill + slice copy + add over the 8-plane image (extension; render() of the package does the same)
+        # (--unfused only) allmap[2:5] as an output tap: the reflection pass's normal gradient reaches the tile backward as its own pointer
+        # instead of through autograd's zero-fill + slice copy + add over the 8-plane image
         self.rasterizer.set_output_taps(("normal_view",))
         # what gaussian_renderer.surface_pass reads from a camera
         self.world_view_transform, self.full_proj_transform = self.ct["viewmatrix"], self.ct["projmatrix"]
@@ -113,6 +115,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mu", type=float, default=-4.75)
+    ap.add_argument("--heavy-mu", type=float, default=-4.4,
+                    help="log-scale mean of the second, heavier C3-shaped line (c3_heavy): SURVEY.md 8d calibrates the scenes for ~6 tiles per Gaussian "
+                         "(R ~ 6 M at 1 M Gaussians); mu = -4.75 gives 3.9")
+    ap.add_argument("--no-heavy", action="store_true", help="N = 1: skip the c3_heavy object")
     ap.add_argument("--cubemap", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary end-to-end (loss + Adam) timing")
@@ -126,6 +132,9 @@ def main():
                     help="views of a rank's batch alternate over this many torch streams: the binning chain of view i+1 (launch-latency-bound) runs beside "
                          "the tile kernels of view i (VALU-bound); the backwards stay ordered (they add into one gradient buffer)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in object (reference entry points with plain autograd)")
+    ap.add_argument("--unfused", action="store_true",
+                    help="rasterizer and deferred reflection as two autograd nodes / two more kernels per direction (rounds 1-3) instead of the fused "
+                         "rasterize + reflect path (the reflection's pixel code inside the tile kernels)")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="N > 1, full_train_step: reduce-scatter -> Adam on this rank's 1/N of the flat buffer -> all-gather instead of all-reduce -> full Adam")
     args = ap.parse_args()
@@ -169,7 +178,7 @@ def main():
 
     import gsr_synth as S
     import _gsr
-    from gaussian_renderer import deferred_reflection
+    from gaussian_renderer import deferred_reflection, rasterize_reflect
     from gsr_dist import shard_views
 
     if args.only_c5:
@@ -187,22 +196,30 @@ def main():
         raise SystemExit("bench: fewer views per step (%d) than ranks (%d)" % (views_total, world))
     scene = Scene(S, P, args.mu, args.cubemap, dev, seed=1003)
     views = [View(S, v, W, H, dev) for v in my_views]
-    env = EnvMap(scene.p["cubemap"], scene.p["fail"])
+    env = scene.env
     g = S.make_upstream_grads(H, W, 1003)
     g_final = torch.from_numpy(g["dL_dcolor"]).to(dev)
     g_allmap = torch.from_numpy(g["dL_dplanes"]).to(dev)
-    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    means2D = scene.means2D
     info = {}
 
-    def render(view, refl_sink, accumulate):
+    def render(view, refl_sink, accumulate, sc=None):
+        sc = sc or scene
         ct = view.ct
-        base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(means3D=scene.p["means3D"], means2D=means2D, opacities=scene.p["opacities"],
-                                                            shs=scene.p["shs"], refl_strengths=scene.p["refl_strengths"],
-                                                            scales=scene.p["scales"], rotations=scene.p["rotations"],
-                                                            env_scope_mask=scene.mask)
-        final, refl_color, nrm = deferred_reflection(normal_view, base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
-                                                     grad_sink=refl_sink, accumulate=accumulate,
-                                                     async_tail=refl_sink is not None and not args.sync_reflection_tail)
+        env, means2D = sc.env, sc.means2D
+        kw = dict(means3D=sc.p["means3D"], means2D=means2D, opacities=sc.p["opacities"], shs=sc.p["shs"], refl_strengths=sc.p["refl_strengths"],
+                  scales=sc.p["scales"], rotations=sc.p["rotations"], env_scope_mask=sc.mask)
+        async_tail = refl_sink is not None and not args.sync_reflection_tail
+        if args.unfused:
+            base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(**kw)
+            final, refl_color, nrm = deferred_reflection(normal_view, base, refl_map, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
+                                                         grad_sink=refl_sink, accumulate=accumulate, async_tail=async_tail)
+        else:
+            # rasterizer + deferred reflection in one pass over the pixels: the reflection's per-pixel code is the epilogue of the forward tile
+            # kernel and the prologue of the backward one (gaussian_renderer.rasterize_reflect, csrc/gsr_refl.hpp)
+            final, refl_color, nrm, base, radii, allmap, refl_map, gw = rasterize_reflect(view.rasterizer, env, ct["viewmatrix"], view.HWK, ct["R"], ct["T"],
+                                                                                         refl_grad_sink=refl_sink, accumulate=accumulate,
+                                                                                         async_tail=async_tail, **kw)
         if base.grad_fn is not None:
             info["R"] = base.grad_fn.num_rendered
         return final, allmap
@@ -216,9 +233,10 @@ def main():
 
     vstreams = [torch.cuda.Stream(device=dev) for _ in range(args.view_streams)] if args.view_streams > 1 else []
 
-    def step_into(buf, reduce, timed=False, batch=None):
+    def step_into(buf, reduce, timed=False, batch=None, sc=None):
         sink, rsink = buf.sink(), buf.sink(names=("cubemap", "fail"))
         vs = views if batch is None else batch
+        means2D = (sc or scene).means2D
         if vstreams and len(vs) > 1:
             main = torch.cuda.current_stream()
             fork = torch.cuda.Event()
@@ -231,7 +249,7 @@ def main():
                 with torch.cuda.stream(st):
                     view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
                     means2D.grad = None
-                    final, allmap = render(view, rsink, i > 0)
+                    final, allmap = render(view, rsink, i > 0, sc)
                     if done:
                         st.wait_event(done[-1])      # the backwards add into ONE buffer: view i's may not start before view i-1's is over
                     torch.autograd.backward([final, allmap], [g_final, g_allmap])
@@ -243,7 +261,7 @@ def main():
             for i, view in enumerate(vs):
                 view.rasterizer.set_grad_sink(sink, accumulate=i > 0)
                 means2D.grad = None
-                final, allmap = render(view, rsink, i > 0)
+                final, allmap = render(view, rsink, i > 0, sc)
                 torch.autograd.backward([final, allmap], [g_final, g_allmap])
         if not timed:
             return reduce(buf)
@@ -355,25 +373,56 @@ def main():
         torch.cuda.synchronize()
         fwd_step_ms = [fmarks[i].elapsed_time(fmarks[i + 1]) for i in range(nf)]
 
-    # BASELINE C4 on this one GPU (reported, never `value`): the batch of 8 views of the same scene per step — first view overwriting the flat
-    # gradient buffer, seven adding to it on the device — as the N > 1 runs shard it over the ranks
-    c4 = None
-    if world == 1 and views_total == 1 and not args.no_c4:
-        batch = views + [View(S, v, W, H, dev) for v in range(1, 8)]
+    def side_line(sc, batch, nb, what):
+        """A reported (never `value`) line on another scene / batch of views: wall clock over nb synchronised steps, then one instrumented
+        pass for the stage table (per view)."""
         for _ in range(2):
-            step_into(scene.grads, lambda b: b.all_reduce(), batch=batch)
+            step_into(sc.grads, lambda b: b.all_reduce(), batch=batch, sc=sc)
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        nb = max(3, args.steps // 4)
         for _ in range(nb):
-            step_into(scene.grads, lambda b: b.all_reduce(), batch=batch)
+            step_into(sc.grads, lambda b: b.all_reduce(), batch=batch, sc=sc)
         torch.cuda.synchronize()
-        c4_ms = (time.perf_counter() - tc) / nb * 1e3
-        c4 = {"workload": "C4 on one GPU: a batch of 8 views (yaw 0..21 degrees) of the C3 scene per step, gradients accumulated on the device in the flat buffer",
-              "ms_per_step": round(c4_ms, 4), "ms_per_view": round(c4_ms / 8, 4), "views_per_s": round(8e3 / c4_ms, 2), "steps": nb}
-        for view in batch[1:]:
+        ms = (time.perf_counter() - tc) / nb * 1e3
+        _gsr.profile_enable(True)
+        for _ in range(nb):
+            step_into(sc.grads, lambda b: b.all_reduce(), batch=batch, sc=sc)
+        torch.cuda.synchronize()
+        st = _gsr.profile_collect()
+        _gsr.profile_enable(False)
+        nvw = len(batch)
+        out = {"workload": what, "ms_per_step": round(ms, 4), "ms_per_view": round(ms / nvw, 4), "views_per_s": round(nvw * 1e3 / ms, 2), "steps": nb,
+               "num_rendered": info.get("R"), "stage_ms_per_view": {k: round(v[0] / max(1, nb * nvw), 4) for k, v in st.items() if v[1] > 0}}
+        for view in batch:
             view.rasterizer.set_grad_sink(None)
-        del batch
+        return out
+
+    # BASELINE C4 on this one GPU (reported, never `value`), with the geometry SURVEY.md 8d fixes for it: 1e6 surfels in the ball of radius 2
+    # about the origin, eight cameras on a circle of radius 5 looking at it — one step = the batch of 8 views, first view overwriting the flat
+    # gradient buffer, seven adding to it on the device, as the N > 1 runs shard it over the ranks.  (The N > 1 headline keeps the C3 scene
+    # with eight yawed cameras, so that the driver's efficiency = value(N) / (N value(1)) compares like with like.)
+    c4 = heavy = None
+    if world == 1 and views_total == 1 and not args.no_c4:
+        ball = Scene(S, P, args.mu, args.cubemap, dev, seed=1004, ball=True)
+        batch = [View(S, k, W, H, dev, cam=c) for k, c in enumerate(S.circle_cameras(W, H, 8))]
+        c4 = side_line(ball, batch, max(3, args.steps // 4),
+                       "C4 on one GPU (SURVEY.md 8d geometry): 1M surfels in the ball of radius 2, a batch of 8 views from cameras on a circle of radius 5 "
+                       "per step, gradients accumulated on the device in the flat buffer")
+        ball.release()
+        del ball, batch
+        torch.cuda.empty_cache()
+    # A second, heavier C3-shaped line: the same step on a scene calibrated for ~6 tiles per Gaussian (every tuning decision of rounds 1-3 was
+    # taken at 3.9).  Never `value`.
+    if world == 1 and views_total == 1 and not args.no_heavy:
+        hv = Scene(S, P, args.heavy_mu, args.cubemap, dev, seed=1003)
+        heavy = side_line(hv, [View(S, 0, W, H, dev)], max(5, args.steps // 2),
+                          "C3-shaped, heavier: 1M surfels with log-scale mean mu = %.2f (C3: %.2f), 1920x1080, SH 3 + reflection path, fwd+bwd, one view per step"
+                          % (args.heavy_mu, args.mu))
+        heavy["tiles_per_gaussian"] = round(heavy["num_rendered"] / P, 2)
+        hv.release()
+        del hv
+        torch.cuda.empty_cache()
+    info["R"] = None
 
     scene_payload_mb = scene.grads.flat.numel() * 4 / 1e6
     full = None if args.no_full_step else full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, world, views_total)
@@ -430,7 +479,7 @@ def main():
                 roof["bound2"]["issue_bound_of_this_mix"] = {
                     "avg_ns_per_valu_instruction": mix["avg_ns_per_valu"], "static_mix_of_the_hot_loop": mix["mix"], "bound_ms": round(bound_ms, 4),
                     "frac": round(bound_ms / (launch_s * 1e3), 4), "frac_alone": round(bound_ms / alone_ms, 4) if alone_ms else None,
-                    "source": "profiles/r03_isa_mix.json (tests/isa_mix.py, same build digest) x SQ_INSTS_VALU of the PMC pass"}
+                    "source": "profiles/r04_isa_mix.json (tests/isa_mix.py, same build digest) x SQ_INSTS_VALU of the PMC pass"}
         out = {
             "metric": "train_step_views_per_s (fwd+bwd, 1e6 Gaussians @1080p, surfel rasterizer + reflection path)",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -442,7 +491,9 @@ def main():
                        "gaussians": P, "width": W, "height": H, "num_rendered": R, "views_per_step": views_total,
                        "views_per_step_per_gpu": nv,
                        "parallelism": ("views sharded %d per GPU, gradients accumulated on device, all-reduce inside the step" % nv) if dist_on
-                       else "single GPU"},
+                       else "single GPU",
+                       "reflection": "two nodes: rasterizer, then deferred_reflection (--unfused)" if args.unfused else
+                                     "fused: the deferred reflection's pixel code runs inside the rasterizer's tile kernels (rasterize_reflect)"},
             "step_ms": percentiles(step_ms),
             "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4), "forward_step_ms": percentiles(fwd_step_ms),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
@@ -467,6 +518,8 @@ def main():
                                 "xgmi_model_ms": xgmi_model_ms(scene_payload_mb, world)}
         if c4 is not None:
             out["c4_one_gpu"] = c4
+        if heavy is not None:
+            out["c3_heavy"] = heavy
         if full is not None:
             out["full_train_step"] = full
         if not args.no_c5 and world == 1:
@@ -477,6 +530,11 @@ def main():
             out["dropin"] = dropin_object(args, S, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(S, P, W, H, args.mu, args.cubemap)
+            if "c5" in out:
+                try:
+                    out["c5"]["cpu_baseline"] = cpu_baseline_c5(S)
+                except Exception as ex:
+                    out["c5"]["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
@@ -529,7 +587,7 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
     rank's views: render -> (1 - lambda) L1 + lambda (1 - SSIM) against a synthetic ground-truth image -> backward (gradients
     accumulated on the device) -> gradient all-reduce -> Adam over all eight parameter groups.  Never `value`."""
     import _gsr
-    from gaussian_renderer import deferred_reflection, surface_pass
+    from gaussian_renderer import deferred_reflection, rasterize_reflect, surface_pass
     from gsr_train import DEFAULT_LRS, GaussianTrainState
     from utils.loss_utils import normal_consistency_loss, photometric_loss
     H, W = args.height, args.width
@@ -556,11 +614,16 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
         for i, view in enumerate(views):
             view.rasterizer.set_grad_sink(fsink, accumulate=i > 0)
             means2D.grad = None
-            base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"],
-                                                                shs=st.p["shs"], refl_strengths=st.p["refl_strengths"], scales=st.p["scales"],
-                                                                rotations=st.p["rotations"], env_scope_mask=mask)
-            final, _, rend_normal = deferred_reflection(normal_view, base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
-                                              grad_sink=frsink, accumulate=i > 0, async_tail=not args.sync_reflection_tail)
+            kw = dict(means3D=st.p["means3D"], means2D=means2D, opacities=st.p["opacities"], shs=st.p["shs"], refl_strengths=st.p["refl_strengths"],
+                      scales=st.p["scales"], rotations=st.p["rotations"], env_scope_mask=mask)
+            if args.unfused:
+                base, radii, allmap, refl_map, gw, normal_view = view.rasterizer(**kw)
+                final, _, rend_normal = deferred_reflection(normal_view, base, refl_map, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"],
+                                                            grad_sink=frsink, accumulate=i > 0, async_tail=not args.sync_reflection_tail)
+            else:
+                final, _, rend_normal, base, radii, allmap, refl_map, gw = rasterize_reflect(
+                    view.rasterizer, fenv, view.ct["viewmatrix"], view.HWK, view.ct["R"], view.ct["T"], refl_grad_sink=frsink, accumulate=i > 0,
+                    async_tail=not args.sync_reflection_tail, **kw)
             # the reference's iteration (train.py:144-196): surface pass of render(), photometric + normal-consistency loss
             surf_depth, surf_normal = surface_pass(allmap, view, 0.0)
             loss = photometric_loss(final, gt_image, 0.2) + normal_consistency_loss(rend_normal, surf_normal, 0.05)
@@ -692,16 +755,20 @@ def dropin_object(args, S, dev):
             "render_fast_calls": n}
 
 
-def c5_object(S, dev, steps=5):
+def c5_object(S, dev, steps=20):
     """BASELINE config C5 on this GPU: 5e6 Gaussians, 1920x1080, SH 3, the 3DGS rasterizer (variant G) with anti-aliasing and the
-    inverse-depth (depth-regularisation) backward enabled, forward + backward.  Per-stage hipEvent times and the HBM
-    roofline of its two dominant backward kernels (algorithmic bytes: SURVEY.md §8d, variant G)."""
+    inverse-depth (depth-regularisation) backward enabled, forward + backward.  Round 4: the parameter gradients go through gradient
+    sinks into one flat buffer as in the C3 step (variant G has them now); the plain-autograd form of rounds 1-3 is timed beside it
+    with the caching allocator's counters per step, which is what names the 60-ms step a driver run of round 3 contained.  Per-stage
+    hipEvent times and the HBM roofline of the two dominant backward kernels (algorithmic bytes: SURVEY.md §8d, variant G)."""
     import _gsr
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gsr_dist import FlatGrads
     P, W, H = 5_000_000, 1920, 1080
     sc = S.make_scene(P, "G", seed=1005, mu=-5.3)
     cam = S.make_camera(W, H)
-    t = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths", "normals")}
+    names = ("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths", "normals")
+    t = {k: torch.from_numpy(sc[k]).to(dev).requires_grad_(True) for k in names}
     ct = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in cam.items() if isinstance(v, np.ndarray)}
     del sc
     rast = GaussianRasterizer(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
@@ -713,47 +780,131 @@ def c5_object(S, dev, steps=5):
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     R = [0]
 
+    plain = [True]
+
     def step():
-        for x in list(t.values()) + [means2D]:
-            x.grad = None
+        means2D.grad = None
+        if plain[0]:            # plain autograd: the parameter gradients of the last step are dropped, new ones allocated by the backward
+            for x in t.values():
+                x.grad = None
         color, radii, invd, nmap, rmap = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"], normals=t["normals"],
                                               refl_strengths=t["refl_strengths"], scales=t["scales"], rotations=t["rotations"])
         R[0] = color.grad_fn.num_rendered
         torch.autograd.backward([color, invd, nmap, rmap], [gc, gi, gn, gr])
 
+    def timed(n):
+        """n steps, each timed on its own (wall clock, synchronised) with the caching allocator's counters around it"""
+        per_step, allocs = [], []
+        for _ in range(n):
+            m0 = torch.cuda.memory_stats(dev)
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - t0) * 1e3)
+            m1 = torch.cuda.memory_stats(dev)
+            d = {k: int(m1.get(k, 0) - m0.get(k, 0)) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free")}
+            d["allocated_MB"] = round((m1.get("allocated_bytes.all.allocated", 0) - m0.get("allocated_bytes.all.allocated", 0)) / 1e6, 1)
+            allocs.append(d)
+        return per_step, allocs
+
+    # ---- plain autograd (rounds 1-3): ~2 GB of gradient tensors allocated per step, freed when the next step drops .grad
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    plain_ms, plain_alloc = timed(max(5, steps // 2))
+    for x in t.values():
+        x.grad = None
+    plain[0] = False
+    # ---- gradient sinks: the per-Gaussian backward writes the seven parameter gradients into one flat buffer
+    fg = FlatGrads(t)
+    rast.set_grad_sink(fg.sink(), accumulate=False)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
     _gsr.profile_enable(True)
-    per_step = []
-    for _ in range(steps):          # every step timed on its own (wall clock, synchronised), median reported: plain autograd allocates ~2 GB of
-        t0 = time.perf_counter()    # gradient tensors per step here and one slow allocation used to dominate a five-step mean
-        step()
-        torch.cuda.synchronize()
-        per_step.append((time.perf_counter() - t0) * 1e3)
+    per_step, sink_alloc = timed(steps)
     ms = sorted(per_step)[len(per_step) // 2]
     st = _gsr.profile_collect()
     _gsr.profile_enable(False)
     stage = {k: round(v[0] / steps, 4) for k, v in st.items() if v[1] > 0}
     HW = W * H
+    # Gaussians whose colour gradient is non-zero: the per-Gaussian backward reads the 192-byte SH row only for those (it still writes the
+    # zero rows of dL_dsh in overwrite mode), so the bytes it MOVES follow from the data, not from P alone
+    n_color = int((fg.view("shs")[:, 0, :] != 0).any(dim=1).sum().item())
     kernels = {}
-    for name, key, nbytes in (("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P), ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW)):
+    for name, key, upper, moved, why in (
+            ("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P, 639 * P - 192 * (P - n_color),
+             "639 B per Gaussian (SURVEY.md 8d) minus the 192-byte SH row of the %d of %d Gaussians whose colour gradient is zero (not read)" % (P - n_color, P)),
+            ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW, 124 * R[0] + 40 * HW, "124 B per instance + 40 B per pixel (SURVEY.md 8d)")):
         if stage.get(key):
-            gbs = nbytes / (stage[key] * 1e-3) / 1e9
             pmc = pmc_summary(name, P, W, H, PMC_FILE_C5)
-            kernels[name] = {"bound": "hbm", "avg_launch_ms": stage[key], "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(gbs, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                             "frac_of_measured_ceiling": round(gbs / HBM_MEASURED_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source")}
-    del t, means2D
+            kernels[name] = roofline_entry(stage[key], moved, upper, why, pmc)
+    del t, means2D, fg
     torch.cuda.empty_cache()
-    return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd", "num_rendered": R[0],
-            "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps, "stage_ms_per_step": stage, "kernel_sum_ms": round(sum(stage.values()), 4), "roofline": kernels}
+    return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd; parameter gradients through "
+                        "gradient sinks into one flat buffer (as the C3 step)", "num_rendered": R[0],
+            "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps, "stage_ms_per_step": stage,
+            "kernel_sum_ms": round(sum(stage.values()), 4), "step_over_kernel_sum": round(ms / max(1e-9, sum(stage.values())), 4),
+            "allocator_per_step": {"what": "torch.cuda.memory_stats() deltas around each synchronised step (caching allocator): num_device_alloc > 0 or "
+                                           "num_alloc_retries > 0 inside the loop means the step went to hipMalloc / freed cached blocks and retried",
+                                   "sinks": sink_alloc, "plain_autograd": plain_alloc},
+            "plain_autograd": {"ms_per_step": round(sorted(plain_ms)[len(plain_ms) // 2], 4), "ms_per_step_all": [round(x, 3) for x in plain_ms],
+                               "what": "the same step with the ~2 GB of parameter gradients allocated by autograd every step (rounds 1-3)"},
+            "roofline": kernels}
+
+
+def roofline_entry(ms, moved, upper, why, pmc):
+    """HBM roofline of one kernel launch: `achieved` = the bytes the kernel MOVES by its algorithm for THIS input (where a kernel skips work
+    by data, `moved` < `algorithmic_upper`, the SURVEY.md 8d figure for an input in which nothing is skipped) / its hipEvent-measured
+    launch time; `traffic` = HBM bytes of the committed PMC pass (null when that pass belongs to another build) with the rate it implies.
+    A fraction of the measured copy ceiling above 1 would mean the kernel is credited with bytes it does not move: flagged, never hidden."""
+    gbs = moved / (ms * 1e-3) / 1e9
+    e = {"bound": "hbm", "avg_launch_ms": ms, "algorithmic_bytes_per_launch": int(moved), "algorithmic_upper": int(upper), "bytes_note": why,
+         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+         "frac_of_measured_ceiling": round(gbs / HBM_MEASURED_GBS, 4), "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source")}
+    if pmc.get("traffic"):
+        tg = pmc["traffic"] / (ms * 1e-3) / 1e9
+        e["traffic_GBps"] = round(tg, 1)
+        e["traffic_frac_of_peak"] = round(tg / HBM_PEAK_GBS, 4)
+    if e["frac_of_measured_ceiling"] > 1.0:
+        e["inconsistent"] = "achieved exceeds the measured copy ceiling: the byte count credits traffic the kernel does not move"
+    return e
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_c5(S):
+    """The CPU oracle (variant G, anti-aliasing, inverse-depth backward) on a bounded sample of C5 with all host cores: 1/4 of the step with the
+    same per-tile statistics (Gaussians / 4, image / 2 per side, scales x 2), extrapolated x 4."""
+    from oracle import oracle as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import scene_kwargs
+    f = 2
+    P, W, H, mu = 5_000_000 // (f * f), 1920 // f, 1080 // f, -5.3 + math.log(f)
+    kw, cam, sc = scene_kwargs("G", P, W, H, 1005, mu, 3, (0, 0, 0))
+    g = S.make_upstream_grads(H, W, 1005)
+    o = orc.GaussOracle(np.float32)
+    t = time.perf_counter()
+    ref = o.forward(antialiasing=True, **kw)
+    o.backward(dL_dcolor=g["dL_dcolor"], dL_dinvdepth=g["dL_dinvdepth"], dL_dnormal_map=g["dL_dnormal"], dL_drefl_strength_map=g["dL_drefl"])
+    dt = time.perf_counter() - t
+    return {"value": round(1.0 / (dt * f * f), 4), "unit": "views/s", "cores": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+            "sample": "1/%d of C5 with the same per-tile statistics (%d Gaussians, scales x %d, %dx%d, R=%d) through the CPU oracle (OpenMP, all host "
+                      "cores), %.1f s, extrapolated x %d" % (f * f, P, f, W, H, ref["num_rendered"], dt, f * f)}
 
 
 def isa_mix(kernel):
-    """Static instruction mix of `kernel`'s hot loop (profiles/r03_isa_mix.json, tests/isa_mix.py), quoted only for the build it was taken on."""
+    """Static instruction mix of `kernel`'s hot loop (profiles/r04_isa_mix.json, tests/isa_mix.py), quoted only for the build it was taken on."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r03_isa_mix.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_mix.json")))
         built = open(DIGEST_FILE).read().strip()
     except (OSError, ValueError):
         return None
@@ -823,8 +974,23 @@ def cpu_baseline(S, P, W, H, mu, L):
         return time.perf_counter() - t, ref["num_rendered"]
 
     dt, R = one_step(P, W, H, mu, 1003)
-    out = {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": "one full C3 step (1M Gaussians, 1920x1080, R=%d) through the CPU oracle (OpenMP, all host cores), %.1f s" % (R, dt)}
+    out = {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+           "sample": "one full C3 step (%d Gaussians, %dx%d, R=%d) through the CPU oracle (OpenMP, all host cores), %.1f s" % (P, W, H, R, dt)}
+    # "C1 and C2 are timed fully on CPU"
+    try:
+        c1, c2 = S.CONFIGS[1], S.CONFIGS[2]
+        kw, _, _ = scene_kwargs("S", c1["P"], c1["W"], c1["H"], 1001, c1["mu"], c1["sh_degree"], (0, 0, 0))
+        o1 = orc.SurfelOracle(np.float32)
+        t = time.perf_counter()
+        r1 = o1.forward(**kw)
+        d1 = time.perf_counter() - t
+        d2, R2 = one_step(c2["P"], c2["W"], c2["H"], c2["mu"], 1002)
+        out["c1"] = {"value": round(1.0 / d1, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                     "sample": "C1 in full: %d surfels, %dx%d, SH degree 0, forward only (R=%d), %.3f s" % (c1["P"], c1["W"], c1["H"], r1["num_rendered"], d1)}
+        out["c2"] = {"value": round(1.0 / d2, 3), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                     "sample": "C2 in full: %d surfels, %dx%d, SH degree 3, forward + backward + cubemap lookup both ways (R=%d), %.2f s" % (c2["P"], c2["W"], c2["H"], R2, d2)}
+    except Exception as ex:     # the headline's baseline above must survive a failure here
+        out["c1_c2_error"] = repr(ex)
     try:
         omp = ctypes.CDLL("libgomp.so.1")
         omp.omp_get_max_threads.restype = ctypes.c_int

@@ -34,6 +34,16 @@ class AdamSegment(ctypes.Structure):
                 ("split", c_uint32)]
 
 
+class ReflForward(ctypes.Structure):
+    """gsr_refl_forward of include/gsr_hip.h."""
+    _fields_ = [("cam", c_void_p), ("cubemap", c_void_p), ("fail_value", c_void_p), ("L", c_uint32), ("cubemap_rgba", c_void_p),
+                ("out_final", c_void_p), ("out_refl_color", c_void_p), ("out_normal_world", c_void_p), ("sort_keys", c_void_p),
+                ("scratch", c_void_p), ("scratch_floats", c_size_t), ("async_sort", c_int)]
+
+
+GSR_ABI_VERSION = 101      # GSR_ABI_VERSION of include/gsr_hip.h this binding was written against
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -43,6 +53,11 @@ def _load():
     P = c_void_p
     lib.gsr_last_error.restype = c_char_p
     lib.gsr_version.restype = c_int
+    if lib.gsr_version() != GSR_ABI_VERSION:
+        # an entry point never changes its signature, but a library built from another header may lack (or, once, have changed) symbols
+        # this binding calls: refuse it instead of passing shifted arguments
+        raise ImportError(f"{LIB_PATH} reports ABI version {lib.gsr_version()}, this binding was written against {GSR_ABI_VERSION} "
+                          f"(include/gsr_hip.h): rebuild with `python {os.path.join(_HERE, 'csrc', 'build.py')} --force`")
     lib.gsr_surfel_forward.restype = c_int
     lib.gsr_surfel_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
                                        c_float, c_float, c_int, P, P, P, P, P, c_int, P]
@@ -53,12 +68,16 @@ def _load():
     lib.gsr_surfel_backward_accum.argtypes = lib.gsr_surfel_backward.argtypes[:-2] + [c_int, c_int, P]
     lib.gsr_surfel_backward_ex.restype = c_int
     lib.gsr_surfel_backward_ex.argtypes = lib.gsr_surfel_backward.argtypes[:-2] + [c_int, P, c_int, P]
+    lib.gsr_surfel_forward_refl.restype = c_int
+    lib.gsr_surfel_forward_refl.argtypes = lib.gsr_surfel_forward.argtypes[:-2] + [ctypes.POINTER(ReflForward), c_int, P]
     lib.gsr_gauss_forward.restype = c_int
     lib.gsr_gauss_forward.argtypes = [ALLOC_FN, P, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P,
                                       c_float, c_float, c_int, P, P, P, P, c_int, P, c_int, P]
     lib.gsr_gauss_backward.restype = c_int
     lib.gsr_gauss_backward.argtypes = [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_float, P, P, P, P, P, c_float,
                                        c_float, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]
+    lib.gsr_gauss_backward_accum.restype = c_int
+    lib.gsr_gauss_backward_accum.argtypes = lib.gsr_gauss_backward.argtypes[:-2] + [c_int, c_int, P]
     lib.gsr_mark_visible.restype = c_int
     lib.gsr_mark_visible.argtypes = [c_int, P, P, P, P, P]
     lib.gsr_debug_fetch.restype = c_int
@@ -76,9 +95,13 @@ def _load():
     lib.gsr_deferred_reflection_backward_accum.restype = c_int
     lib.gsr_deferred_reflection_backward_accum.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, P]
     lib.gsr_deferred_reflection_backward_ex.restype = c_int
-    lib.gsr_deferred_reflection_backward_ex.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P, P, P]
+    lib.gsr_deferred_reflection_backward_ex.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P, P]
+    lib.gsr_deferred_reflection_backward_keys.restype = c_int
+    lib.gsr_deferred_reflection_backward_keys.argtypes = lib.gsr_deferred_reflection_backward.argtypes[:-1] + [c_int, c_int, P, P, c_int, P]
     lib.gsr_deferred_reflection_forward_ex.restype = c_int
-    lib.gsr_deferred_reflection_forward_ex.argtypes = lib.gsr_deferred_reflection_forward.argtypes[:-1] + [P, P, P]
+    lib.gsr_deferred_reflection_forward_ex.argtypes = lib.gsr_deferred_reflection_forward.argtypes[:-1] + [P, P]
+    lib.gsr_deferred_reflection_forward_keys.restype = c_int
+    lib.gsr_deferred_reflection_forward_keys.argtypes = lib.gsr_deferred_reflection_forward.argtypes[:-1] + [P, P, P]
     lib.gsr_side_join.restype = c_int
     lib.gsr_side_join.argtypes = [P]
     lib.gsr_normal_world_forward.restype = c_int
@@ -152,7 +175,8 @@ def compiled_binding():
 PYBIND = compiled_binding()
 
 EXPORTED = ["gsr_last_error", "gsr_version", "gsr_surfel_forward", "gsr_surfel_backward", "gsr_surfel_backward_accum", "gsr_surfel_backward_ex",
-            "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_deferred_reflection_forward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward",
+            "gsr_surfel_forward_refl", "gsr_deferred_reflection_backward_keys", "gsr_deferred_reflection_forward_keys",
+            "gsr_deferred_reflection_backward_accum", "gsr_deferred_reflection_backward_ex", "gsr_deferred_reflection_forward_ex", "gsr_side_join", "gsr_normal_world_forward", "gsr_normal_world_backward", "gsr_gauss_forward", "gsr_gauss_backward", "gsr_gauss_backward_accum",
             "gsr_mark_visible", "gsr_debug_fetch", "gsr_cubemap_forward", "gsr_cubemap_backward", "gsr_deferred_reflection_forward",
             "gsr_deferred_reflection_scratch_floats", "gsr_deferred_reflection_backward", "gsr_ssim_l1_scratch_floats", "gsr_ssim_l1_forward", "gsr_ssim_l1_backward", "gsr_normal_loss_scratch_floats", "gsr_normal_loss_forward", "gsr_normal_loss_backward", "gsr_adam_step", "gsr_adam_step_range", "gsr_densification_stats", "gsr_gather_rows", "gsr_split_children", "gsr_surface_forward", "gsr_surface_backward", "gsr_profile_enable",
             "gsr_profile_collect", "gsr_set_option"]
@@ -165,15 +189,17 @@ def set_option(name, value):
     check(lib.gsr_set_option(name.encode(), int(value)), f"gsr_set_option({name})")
 
 
-_side_held = {}          # device index -> tensors the side stream of THAT device still reads or writes
+_side_held = {}          # device index -> [(tensor the side stream of THAT device still reads or writes, stream it was allocated / last used on)]
 
 
 def side_hold(*tensors):
-    """Keeps device tensors alive that work on the library's side stream still reads (see side_join)."""
+    """Keeps device tensors alive that work on the library's side stream still reads (see side_join), and remembers the stream that is
+    current now — the one the caching allocator will hand their blocks back to."""
     for t in tensors:
         if t is None:
             continue
-        _side_held.setdefault(t.device.index if t.device.index is not None else torch.cuda.current_device(), []).append(t)
+        dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        _side_held.setdefault(dev, []).append((t, torch.cuda.current_stream(t.device).cuda_stream))
 
 
 def side_join(device=None):
@@ -185,11 +211,16 @@ def side_join(device=None):
         dev = torch.device("cuda", torch.cuda.current_device())
     # always ask the library (a stream-wait on an event that has completed, or was never recorded, costs nothing): a second
     # consumer stream must be ordered behind the tail too, and another device's held tensors are none of this call's business
+    held = _side_held.pop(dev.index, [])
     with torch.cuda.device(dev):
-        check(lib.gsr_side_join(torch.cuda.current_stream(dev).cuda_stream), "gsr_side_join")
-    # the tensors go back to the caching allocator, which hands them out again to work on the CURRENT stream: that work is
-    # ordered behind the join just made, so the tail can no longer be reading them
-    _side_held.pop(dev.index, None)
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        check(lib.gsr_side_join(cur), "gsr_side_join")
+        # The held tensors go back to the caching allocator, which re-issues a block to work on the stream it was ALLOCATED on — not
+        # necessarily the stream joining here (an all-reduce or optimizer stream, bench.py --view-streams).  Every such stream is ordered
+        # behind the tail as well, so whatever reuses the memory cannot run while the tail still reads or writes it.
+        for s in {s for _, s in held if s != cur}:
+            check(lib.gsr_side_join(s), "gsr_side_join")
+    del held
 
 
 def profile_enable(on=True):

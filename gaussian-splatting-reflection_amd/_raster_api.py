@@ -192,7 +192,8 @@ def build_api(v: Variant):
             with torch.no_grad():
                 return v.c_module.mark_visible(positions, s.viewmatrix, s.projmatrix)
 
-        def _forward(self, means3D, means2D, opacities, **kw):
+        def _collect(self, means3D, means2D, opacities, **kw):
+            """The reference's argument checks and placeholder substitution; returns the tensors of Function.apply by name."""
             if (kw["shs"] is None) == (kw["colors_precomp"] is None):
                 raise Exception(MSG_COLOR)
             have_sr = kw["scales"] is not None and kw["rotations"] is not None
@@ -203,6 +204,10 @@ def build_api(v: Variant):
             for key, value in kw.items():
                 name = v.module_to_apply.get(key, key)
                 t[name] = v.placeholder(name, means3D.device) if value is None and name in PLACEHOLDERS else value
+            return t
+
+        def _forward(self, means3D, means2D, opacities, **kw):
+            t = self._collect(means3D, means2D, opacities, **kw)
             args = [t[name] for name in v.tensors]
             args.insert(v.settings_pos, self.raster_settings)
             ext = self._grad_sink
@@ -226,4 +231,5 @@ def build_api(v: Variant):
     forward.__signature__ = sig
     forward.__doc__ = "Same arguments and return tuple as the reference's GaussianRasterizer.forward."
     GaussianRasterizer.forward = forward
+    GaussianRasterizer.variant = v
     return Settings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer

@@ -110,8 +110,33 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 #ifndef TILE_SORT_BITS
 #define TILE_SORT_BITS 8
 #endif
-#define TILE_SORT_SHAPE 1024, TILE_SORT_IPT, TILE_SORT_BITS
+#ifndef TILE_SORT_BS
+#define TILE_SORT_BS 1024
+#endif
+#define TILE_SORT_SHAPE TILE_SORT_BS, TILE_SORT_IPT, TILE_SORT_BITS
 static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
+
+// What the depth sort carries as its VALUE (round 4): the Gaussian's index (low word) and its tile rectangle packed to 4 x 8 bits
+// (high word: x0 | y0 << 8 | x1 << 16 | y1 << 24).  Key emission then reads index and rectangle of the Gaussians in depth order as ONE
+// coalesced 8-byte stream; before, it read the 4-byte index coalesced and gathered the 8-byte rectangle through it — a whole line per
+// Gaussian for 8 bytes: 135 MB of traffic against 44 MB of algorithmic bytes at C3, 763 against 180 MB at C5, where the kernel was bound by
+// exactly that.  The first pass reads the rectangles in INDEX order (coalesced, through this iterator); the three further passes move 8
+// instead of 4 bytes of value per Gaussian.  Grids beyond 255 tiles per axis (images beyond 4080 pixels) do not fit 8 bits per
+// coordinate: `packed` = 0 leaves the high word empty and emit_tiles_kernel<true> gathers the rectangle as before.
+struct OrderRect {
+	const uint32_t* rect;
+	int packed;
+	__host__ __device__ unsigned long long operator()(uint32_t i) const {
+		uint32_t hi = 0u;
+		if (packed) {
+			const uint2 r = reinterpret_cast<const uint2*>(rect)[i];
+			hi = (r.x & 0xFFu) | ((r.x >> 16) << 8) | ((r.y & 0xFFu) << 16) | ((r.y >> 16) << 24);
+		}
+		return ((unsigned long long)hi << 32) | (unsigned long long)i;
+	}
+};
+using OrderIn = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, OrderRect, unsigned long long>;
+static OrderIn order_in(const uint32_t* rect, int packed) { return OrderIn(rocprim::counting_iterator<uint32_t>(0), OrderRect{rect, packed}); }
 
 // tiles_touched read through the depth order: element i of the sequence the second scan runs over
 struct TouchedInOrder {
@@ -131,10 +156,10 @@ static size_t scan_part_bytes(size_t P) {
 static size_t depth_sort_bytes(size_t P) {
 	size_t c = 0, d = 0;
 	if (P <= SORT_MAX_ITEMS)
-		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-		                                            (uint32_t*)nullptr, P, 0u, DEPTH_KEY_BITS, 0);
-	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<uint32_t>(0),
-	                                            (uint32_t*)nullptr, P, 0, 31, 0, false);
+		(void)onesweep_sort_pairs<DEPTH_SORT_SHAPE>(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, order_in(nullptr, 0),
+		                                            (unsigned long long*)nullptr, P, 0u, DEPTH_KEY_BITS, 0);
+	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, order_in(nullptr, 0),
+	                                            (unsigned long long*)nullptr, P, 0, 31, 0, false);
 	return std::max(c, d);
 }
 size_t scan_temp_bytes(size_t P) { return scan_part_bytes(P) + depth_sort_bytes(P); }
@@ -163,7 +188,7 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	g.acc = c.take<float>(P * acc_floats);
 	g.flags = c.take<int>(4);
 	g.depth_sorted = c.take<uint32_t>(P);
-	g.order = c.take<uint32_t>(P);
+	g.order = c.take<unsigned long long>(P);
 	g.emit_state_bytes = ((((P + 255) / 256 + 1) * sizeof(unsigned long long)) + 15) & ~(size_t)15;   // (enough for any EMIT_BLOCK >= 256)
 	g.emit_state = c.take<unsigned long long>(g.emit_state_bytes / sizeof(unsigned long long));
 	g.scan_temp = c.take<char>(scan_bytes);
@@ -291,24 +316,40 @@ __device__ __forceinline__ unsigned long long emit_peek(unsigned long long* p) {
 // decoupled look-back over the workgroups in front, wave-parallel), instead of a rocPRIM inclusive_scan in front of this kernel: that
 // scan read tiles_touched through the depth order (a random 4-byte gather per Gaussian) and cost two dispatches, 19 us at C3 and 97 us
 // at C5; the count is the area of the tile rectangle, which this kernel gathers anyway (culled Gaussians carry an empty rectangle).
-__global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ rect,
-                                                         unsigned long long* __restrict__ scan_state,
+template <bool GATHER>
+__global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const unsigned long long* __restrict__ order, const uint32_t* __restrict__ rect,
+                                                         unsigned long long* __restrict__ scan_state, uint32_t* __restrict__ ticket,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
                                                          uint2* __restrict__ ranges, uint32_t tiles, void* sort_clear, size_t sort_clear_bytes,
                                                          unsigned long long* __restrict__ blend_mask, size_t blend_words) {
-	const int i = blockIdx.x * EMIT_BLOCK + threadIdx.x;
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	__shared__ uint32_t s_wsum[EMIT_BLOCK / 64];
 	__shared__ uint32_t s_base;
-	// the rectangle is one 8-byte gather; its area is the number of instances (tiles_touched)
+	__shared__ uint32_t s_bid;
+	// Position of this workgroup in the chained scan below: an atomic TICKET, not blockIdx.x.  The look-back spins until every workgroup
+	// in front has published; that terminates only if those workgroups have started, which the order of the tickets guarantees (a
+	// workgroup holding ticket t exists, hence so do the holders of 0..t-1) and the order of the block ids does not — HIP makes no
+	// promise about dispatch order, and rocPRIM's own Onesweep passes take an atomic block id on gfx950 for the same reason
+	// (gsr_sort.hpp).  One atomic per workgroup on a word the preprocess kernel has cleared.
+	if (threadIdx.x == 0) s_bid = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__syncthreads();
+	const int bid = (int)s_bid;
+	const int i = bid * EMIT_BLOCK + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// index and rectangle of the Gaussian at position i of the depth order: one coalesced 8-byte load (OrderRect); the area of the
+	// rectangle is the number of instances (tiles_touched)
 	const bool valid = i < P;
-	uint32_t idx = 0u, r0 = 0u, r1 = 0u;
+	uint32_t idx = 0u, x0 = 0u, y0 = 0u, x1 = 0u, y1 = 0u;
 	if (valid) {
-		idx = order[i];
-		const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
-		r0 = r.x; r1 = r.y;
+		const unsigned long long ov = order[i];
+		idx = (uint32_t)ov;
+		if (GATHER) {
+			const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
+			x0 = r.x & 0xFFFFu; y0 = r.x >> 16; x1 = r.y & 0xFFFFu; y1 = r.y >> 16;
+		} else {
+			const uint32_t hi = (uint32_t)(ov >> 32);
+			x0 = hi & 0xFFu; y0 = (hi >> 8) & 0xFFu; x1 = (hi >> 16) & 0xFFu; y1 = hi >> 24;
+		}
 	}
-	const uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
 	const uint32_t cnt = (x1 - x0) * (y1 - y0);
 	// (the forward tile kernel only writes the blend masks of the batches it reaches: the rest must read as "nothing blended")
 	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * EMIT_BLOCK) blend_mask[t] = 0ull;
@@ -328,7 +369,6 @@ __global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uin
 	if (wave == 0u) {
 		uint32_t total = 0u;
 		for (uint32_t w = 0; w < EMIT_BLOCK / 64; w++) total += s_wsum[w];
-		const int bid = (int)blockIdx.x;
 		uint32_t prefix = 0u;
 		if (bid == 0) {
 			if (lane == 0u) emit_publish(scan_state, emit_pack(2u, total));
@@ -343,7 +383,7 @@ __global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uin
 				// the nearest workgroup that already knows its inclusive prefix ends the walk; everything nearer must at least have published its count
 				const int stop = done != 0ull ? __ffsll((long long)done) - 1 : 63;
 				const unsigned long long need = stop == 63 ? ~0ull : ((2ull << stop) - 1ull);
-				if ((empty & need) != 0ull) continue;      // somebody nearer has not published yet: look again (workgroups start in id order)
+				if ((empty & need) != 0ull) continue;      // somebody nearer has not published yet: look again (it holds a smaller ticket, so it is running)
 				uint32_t v = (int)lane <= stop ? (uint32_t)st : 0u;
 #pragma unroll
 				for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -498,6 +538,8 @@ static Readback* readback_slot() {
 	return &r;
 }
 
+static int rect_packs(int tiles_x, int tiles_y) { return (tiles_x <= 255 && tiles_y <= 255) ? 1 : 0; }   // see OrderRect
+
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom, const ImageState& img,
                 BinningState* out_binning, int prefiltered, int debug, hipStream_t stream) {
 	Readback* rb = readback_slot();
@@ -533,11 +575,11 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		size_t tmp = geom.depth_sort_bytes;
 		if (own_depth_sort)   // look-back state cleared by the preprocess kernel, digit counts accumulated by gaussian_stats_kernel: four dispatches
 			GSR_HIP_CHECK(onesweep_sort_pairs<DEPTH_SORT_SHAPE>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
-			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, DEPTH_KEY_BITS, stream, true,
+			                                                   order_in(geom.rect, rect_packs(tiles_x, tiles_y)), geom.order, (size_t)P, 0u, DEPTH_KEY_BITS, stream, true,
 			                                                   reinterpret_cast<const uint32_t*>(geom.depth_sort_temp)));
 		else
 			GSR_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(geom.depth_sort_temp, tmp, reinterpret_cast<const uint32_t*>(geom.depths), geom.depth_sorted,
-			                                                   rocprim::counting_iterator<uint32_t>(0), geom.order, (size_t)P, 0u, 31u, stream, false));
+			                                                   order_in(geom.rect, rect_packs(tiles_x, tiles_y)), geom.order, (size_t)P, 0u, 31u, stream, false));
 	}
 	if (mailbox) {
 		// spin on the sequence number the last workgroup of gaussian_stats_kernel stores; the way out, should the store not be seen while
@@ -576,7 +618,9 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
-		emit_tiles_kernel<<<(P + EMIT_BLOCK - 1) / EMIT_BLOCK, EMIT_BLOCK, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, b.tile_keys_unsorted,
+		uint32_t* ticket = reinterpret_cast<uint32_t*>(geom.emit_state + (geom.emit_state_bytes / sizeof(unsigned long long) - 1));   // last state word: never a scan position
+		auto emit = rect_packs(tiles_x, tiles_y) ? emit_tiles_kernel<false> : emit_tiles_kernel<true>;
+		emit<<<(P + EMIT_BLOCK - 1) / EMIT_BLOCK, EMIT_BLOCK, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, ticket, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
 		                                                       16 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
@@ -646,7 +690,7 @@ __global__ void __launch_bounds__(256) gather_rec_kernel(int P, const float* __r
 using namespace gsr;
 
 extern "C" const char* gsr_last_error(void) { return g_err; }
-extern "C" int gsr_version(void) { return 100; }
+extern "C" int gsr_version(void) { return GSR_ABI_VERSION; }
 
 
 extern "C" int gsr_set_option(const char* name, int value) {

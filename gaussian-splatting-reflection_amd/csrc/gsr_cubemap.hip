@@ -10,133 +10,11 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include "gsr_sort.hpp"
 #include <rocprim/iterator/counting_iterator.hpp>
+#include "gsr_refl.hpp"
 
 namespace gsr {
 
 
-
-// ----------------------------------------------------------------------------------------------
-// Face / uv selection (CME cubemapencoder.cu:147-187)
-__device__ __forceinline__ void cube_uv(float x, float y, float z, float& u, float& v, int& index) {
-	int max_dim = 0;
-	const float x_ = fabsf(x), y_ = fabsf(y), z_ = fabsf(z);
-	float max_v = x_;
-	if (y_ > max_v) { max_v = y_; max_dim = 1; }
-	if (z_ > max_v) { max_v = z_; max_dim = 2; }
-	if (max_dim == 0) {
-		u = z / x; v = y / x;
-		if (x >= 0.f) { index = 0; u = -u; v = -v; }
-		else { index = 1; u = -u; }
-	} else if (max_dim == 1) {
-		u = x / y; v = z / y;
-		if (y >= 0.f) { index = 2; }
-		else { index = 3; u = -u; v = -v; }
-	} else {
-		u = x / z; v = y / z;
-		if (z >= 0.f) { index = 4; v = -v; }
-		else { index = 5; }
-	}
-}
-
-// Neighbour-face texel across a cube edge (CME cubemapencoder.cu:66-106), as a small table:
-// for (face, flag in {1,2,4,8}) -> new face and how (x', y') derive from (L-1, 0, x, y, L-1-x, L-1-y).
-// Source selectors: 0 -> 0, 1 -> L-1, 2 -> x, 3 -> y, 4 -> L-1-x, 5 -> L-1-y.
-__device__ __forceinline__ void edge_table(int L, int flag, int& face, int& x, int& y) {
-	// packed as face | sx<<4 | sy<<8, index = face*4 + {flag 1:0, 2:1, 4:2, 8:3}
-	const unsigned short tbl[24] = {
-	    4 | (1 << 4) | (3 << 8), 5 | (0 << 4) | (3 << 8), 3 | (1 << 4) | (2 << 8), 2 | (1 << 4) | (2 << 8),   // face 0
-	    5 | (1 << 4) | (3 << 8), 4 | (0 << 4) | (3 << 8), 3 | (0 << 4) | (4 << 8), 2 | (0 << 4) | (4 << 8),   // face 1
-	    1 | (5 << 4) | (1 << 8), 0 | (3 << 4) | (1 << 8), 4 | (2 << 4) | (1 << 8), 5 | (4 << 4) | (1 << 8),   // face 2
-	    1 | (5 << 4) | (0 << 8), 0 | (3 << 4) | (0 << 8), 4 | (2 << 4) | (0 << 8), 5 | (4 << 4) | (0 << 8),   // face 3
-	    1 | (1 << 4) | (3 << 8), 0 | (0 << 4) | (3 << 8), 3 | (2 << 4) | (0 << 8), 2 | (2 << 4) | (0 << 8),   // face 4
-	    0 | (1 << 4) | (3 << 8), 1 | (0 << 4) | (3 << 8), 3 | (4 << 4) | (1 << 8), 2 | (4 << 4) | (1 << 8)};  // face 5
-	const int fi = flag == 1 ? 0 : (flag == 2 ? 1 : (flag == 4 ? 2 : 3));
-	const unsigned e = tbl[face * 4 + fi];
-	const int ix = x, iy = y;
-	auto sel = [&](unsigned s) -> int {
-		switch (s) {
-			case 0: return 0;
-			case 1: return L - 1;
-			case 2: return ix;
-			case 3: return iy;
-			case 4: return L - 1 - ix;
-			default: return L - 1 - iy;
-		}
-	};
-	face = e & 15;
-	x = sel((e >> 4) & 15);
-	y = sel((e >> 8) & 15);
-}
-
-struct Seamless {
-	int f[4], x[4], y[4];  // texel 0: v00, 1: v01 (u neighbour), 2: v10 (v neighbour), 3: v11
-	float kx, ky;
-	int flag;
-	bool is_vertex;
-};
-// Compute_Seamless_Index (CME cubemapencoder.cu:189-263)
-__device__ __forceinline__ void seamless_index(int index, int L, float u, float v, Seamless& s) {
-	float lu = u, lv = -v;
-	lu = (lu * 0.5f + 0.5f) * (float)L;
-	lv = (lv * 0.5f + 0.5f) * (float)L;
-	int ux_0 = (int)floorf(lu - 0.5f), uy_0 = (int)floorf(lv - 0.5f);
-	int ux_1 = ux_0 + 1, uy_1 = uy_0 + 1;
-	float kx = lu - (float)ux_0 - 0.5f;
-	float ky = lv - (float)uy_0 - 0.5f;
-	ux_0 = min(max(ux_0, 0), L - 1); ux_1 = min(max(ux_1, 0), L - 1);
-	uy_0 = min(max(uy_0, 0), L - 1); uy_1 = min(max(uy_1, 0), L - 1);
-	int flag = 0;
-	if (lu < 0.5f) { flag |= 1; kx = 0.5f - lu; }
-	else if (lu >= (float)L - 0.5f) flag |= 2;
-	if (lv < 0.5f) { flag |= 4; ky = 0.5f - lv; }
-	else if (lv >= (float)L - 0.5f) flag |= 8;
-	s.is_vertex = false;
-	for (int i = 0; i < 4; i++) { s.f[i] = index; s.x[i] = ux_0; s.y[i] = uy_0; }
-	if ((flag & 3) && (flag & 12)) {
-		s.is_vertex = true;
-		edge_table(L, flag & 3, s.f[1], s.x[1], s.y[1]);
-		edge_table(L, flag & 12, s.f[2], s.x[2], s.y[2]);
-	} else if (flag & 3) {
-		edge_table(L, flag, s.f[1], s.x[1], s.y[1]);
-		s.y[2] = uy_1;
-		s.y[3] = uy_1;
-		edge_table(L, flag, s.f[3], s.x[3], s.y[3]);
-	} else if (flag & 12) {
-		s.x[1] = ux_1;
-		edge_table(L, flag, s.f[2], s.x[2], s.y[2]);
-		s.x[3] = ux_1;
-		edge_table(L, flag, s.f[3], s.x[3], s.y[3]);
-	} else {
-		s.x[1] = ux_1;
-		s.y[2] = uy_1;
-		s.x[3] = ux_1; s.y[3] = uy_1;
-	}
-	s.kx = kx; s.ky = ky; s.flag = flag;
-}
-
-// Compute_Cubemap_UV_Backward (CME cubemapencoder.cu:265-292); (gu, gv) are modified as there.
-__device__ __forceinline__ void cube_uv_backward(int index, float x, float y, float z, float gu, float gv, float& gx, float& gy, float& gz) {
-	const int face = index / 2;
-	if (face == 0) {
-		if (index == 0) { gu = -gu; gv = -gv; }
-		else { gu = -gu; }
-		gx = -(z * gu + y * gv) / (x * x);
-		gy = 1.f / x * gv;
-		gz = 1.f / x * gu;
-	} else if (face == 1) {
-		if (index != 2) { gu = -gu; gv = -gv; }
-		gx = 1.f / y * gu;
-		gy = -(x * gu + z * gv) / (y * y);
-		gz = 1.f / y * gv;
-	} else {
-		if (index == 4) { gv = -gv; }
-		gx = 1.f / z * gu;
-		gy = 1.f / z * gv;
-		gz = -(x * gu + y * gv) / (z * z);
-	}
-}
-
-__device__ __forceinline__ size_t texel(int f, int c, int y, int x, int C, int L) { return (((size_t)f * C + c) * L + y) * L + x; }
 
 // Plain (non-seamless) footprint shared by the bilinear and nearest modes (CME cubemapencoder.cu:356-378, 409-422)
 struct Plain {
@@ -290,43 +168,6 @@ cubemap_bwd_kernel(const float* __restrict__ grad_outputs, const float* __restri
 }
 
 // ----------------------------------------------------------------------------------------------
-// Fused deferred reflection.  cam block (floats):
-//   [0..8]   world_view_transform[:3,:3], row-major (wvt[j][i] at 3*j+i)
-//   [9..17]  K^-1, row-major
-//   [18..26] Rw = R.T of the camera's stored R (= world-to-camera rotation), row-major
-//   [27..29] T (world-to-camera translation)        [30..32] rays_o = -Rw^T T (camera centre)
-struct ReflPixel {
-	float nwx, nwy, nwz, len;   // un-normalised world normal and its length
-	float nx, ny, nz;           // normalised (/(len + 1e-6))
-	float dx, dy, dz;           // unit view ray
-	float dn;                   // d . n
-	float rx, ry, rz;           // reflected ray
-};
-__device__ __forceinline__ void refl_pixel(const float* __restrict__ cam, float nvx, float nvy, float nvz, int px, int py, ReflPixel& o) {
-	// gaussian_renderer/__init__.py:148 : n_world_j = sum_i n_view_i * wvt[j][i]
-	o.nwx = nvx * cam[0] + nvy * cam[1] + nvz * cam[2];
-	o.nwy = nvx * cam[3] + nvy * cam[4] + nvz * cam[5];
-	o.nwz = nvx * cam[6] + nvy * cam[7] + nvz * cam[8];
-	o.len = sqrtf(o.nwx * o.nwx + o.nwy * o.nwy + o.nwz * o.nwz);
-	const float inv = 1.0f / (o.len + 1e-6f);   // :179
-	o.nx = o.nwx * inv; o.ny = o.nwy * inv; o.nz = o.nwz * inv;
-	// utils/general_utils.py:186-196
-	const float x = (float)px, y = (float)py;
-	const float pcx = cam[9] * x + cam[10] * y + cam[11] - cam[27];
-	const float pcy = cam[12] * x + cam[13] * y + cam[14] - cam[28];
-	const float pcz = cam[15] * x + cam[16] * y + cam[17] - cam[29];
-	float wx = pcx * cam[18] + pcy * cam[21] + pcz * cam[24] - cam[30];
-	float wy = pcx * cam[19] + pcy * cam[22] + pcz * cam[25] - cam[31];
-	float wz = pcx * cam[20] + pcy * cam[23] + pcz * cam[26] - cam[32];
-	const float dl = sqrtf(wx * wx + wy * wy + wz * wz);
-	o.dx = wx / dl; o.dy = wy / dl; o.dz = wz / dl;
-	o.dn = o.dx * o.nx + o.dy * o.ny + o.dz * o.nz;
-	o.rx = o.dx - 2 * o.nx * o.dn;   // gaussian_renderer/__init__.py:22-24
-	o.ry = o.dy - 2 * o.ny * o.dn;
-	o.rz = o.dz - 2 * o.nz * o.dn;
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-
 // The pixel kernels gather the four bilinear corners of three channels: twelve 4-byte gathers per pixel from the
 // reference's planar [6][3][L][L] layout, and the texture (1.2 MB at L = 128) does not live in a 32 KB L1 — 9 M L2 read
 // requests per launch at 1080p (TCP_TCC_READ_REQ), which is what bounds a 60 us kernel.  With a texel-interleaved copy
@@ -338,28 +179,6 @@ __global__ void __launch_bounds__(256) cubemap_interleave_kernel(const float* __
 	const size_t f = t / LL, r = t - f * LL;
 	rgba[t] = make_float4(cubemap[(f * 3 + 0) * LL + r], cubemap[(f * 3 + 1) * LL + r], cubemap[(f * 3 + 2) * LL + r], 0.f);
 }
-// corner k of the seamless lookup, all three channels (the fourth corner of a cube vertex is the mean of the other three)
-template <bool RGBA>
-__device__ __forceinline__ void fetch_corners(const Seamless& s, int L, const float* __restrict__ cubemap, const float4* __restrict__ rgba, float (&v)[4][3]) {
-	const int nk = s.is_vertex ? 3 : 4;
-#pragma unroll
-	for (int k = 0; k < 4; k++) {
-		if (k < nk) {
-			if (RGBA) {
-				const float4 t = rgba[((size_t)s.f[k] * L + s.y[k]) * L + s.x[k]];
-				v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z;
-			} else {
-#pragma unroll
-				for (int c = 0; c < 3; c++) v[k][c] = cubemap[texel(s.f[k], c, s.y[k], s.x[k], 3, L)];
-			}
-		}
-	}
-	if (s.is_vertex) {
-#pragma unroll
-		for (int c = 0; c < 3; c++) v[3][c] = (v[0][c] + v[1][c] + v[2][c]) / 3.f;
-	}
-}
-
 template <bool RGBA>
 __global__ void __launch_bounds__(256)
 deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
@@ -369,40 +188,21 @@ deferred_refl_fwd_kernel(const float* __restrict__ normal_view, const float* __r
 	const size_t HW = (size_t)W * H;
 	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (pix >= HW) return;
-	uint32_t key = no_key;
 	const int py = (int)(pix / W), px = (int)(pix - (size_t)py * W);
 	// loads that do not depend on the reflected direction are issued together with the normal (one memory round trip less
 	// per wave; the kernel is a chain of dependent round trips at five waves per SIMD)
 	const float nvx = normal_view[pix], nvy = normal_view[HW + pix], nvz = normal_view[2 * HW + pix];
 	const float sv = strength[pix];
 	const float b0 = base[pix], b1 = base[HW + pix], b2 = base[2 * HW + pix];
-	ReflPixel o;
-	refl_pixel(cam, nvx, nvy, nvz, px, py, o);
-	float c[3];
-	if (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f) {
-		c[0] = fail_value[0]; c[1] = fail_value[1]; c[2] = fail_value[2];
-	} else {
-		float u, v;
-		int face;
-		cube_uv(o.rx, o.ry, o.rz, u, v, face);
-		Seamless s;
-		seamless_index(face, L, u, v, s);
-		float cv[4][3];
-		fetch_corners<RGBA>(s, L, cubemap, rgba, cv);
-#pragma unroll
-		for (int ch = 0; ch < 3; ch++)
-			c[ch] = (1 - s.ky) * ((1 - s.kx) * cv[0][ch] + s.kx * cv[1][ch]) + s.ky * ((1 - s.kx) * cv[2][ch] + s.kx * cv[3][ch]);
-		// sort key of the backward's footprint record (deferred_refl_bwd_entries_kernel): the texel of the upper-left corner when the 2x2
-		// footprint lies inside one face.  It depends on forward data only, so the sort can run beside the backward's pixel kernel.
-		if (s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1) key = (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
-	}
-	if (sort_keys) sort_keys[pix] = key;
-	const float bs[3] = {b0, b1, b2};
+	ReflFwdOut o;
+	refl_forward_pixel<RGBA>(cam, cubemap, rgba, fail_value, L, nvx, nvy, nvz, px, py, sv, b0, b1, b2, no_key, o);   // (gsr_refl.hpp)
+	// sort key of the backward's footprint record (deferred_refl_bwd_entries_kernel): it depends on forward data only, so the sort can
+	// run beside the backward's pixel kernel
+	if (sort_keys) sort_keys[pix] = o.key;
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
-		const float rc = sigmoidf_(c[ch]);
-		out_refl[ch * HW + pix] = rc;
-		out_final[ch * HW + pix] = (1 - sv) * bs[ch] + sv * rc;
+		out_refl[ch * HW + pix] = o.refl_c[ch];
+		out_final[ch * HW + pix] = o.final_c[ch];
 	}
 	out_nworld[pix] = o.nx;
 	out_nworld[HW + pix] = o.ny;
@@ -527,25 +327,18 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 	float gnz = -2.f * (o.dn * grz + grn * o.dz);
 	if (g_nworld) { gnx += g_nworld[p]; gny += g_nworld[HW + p]; gnz += g_nworld[2 * HW + p]; }
 	// n = nw / (|nw| + eps): g_nw = g_n / (len+eps) - nw (nw.g_n) / (len (len+eps)^2)   (0 subgradient at len = 0)
-	const float inv = 1.0f / (o.len + 1e-6f);
+	const float inv = refl_rcp(o.len + 1e-6f);      // (the same reciprocal forms as refl_backward_pixel, gsr_refl.hpp)
 	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
 	if (o.len > 0.f) {
-		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv / o.len;
+		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv * refl_rcp(o.len);
 		gwx -= o.nwx * k; gwy -= o.nwy * k; gwz -= o.nwz * k;
 	}
 	if (chan) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
 }
 
 // The same backward for the sorted-footprint path (`binned` in the C ABI), one lane per pixel: nothing here needs the four lanes of the quad version (they
-// exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  A pixel whose bilinear
-// footprint lies inside one cube face (all but the half-texel rim, ~2/L of the pixels) emits ONE record {g_r, g_g, g_b, kx,
-// ky} plus the sort key "texel id of the upper-left corner": the other corners are t+1, t+L, t+L+1 and the four weights
-// follow from (kx, ky).  Rim pixels (footprints that wrap onto a neighbouring face, cube vertices) add their corners to
-// the staging buffer directly.
-struct alignas(32) ReflFootprint {
-	float g[3], kx, ky;   // 20 bytes used; padded so that a record never straddles a 32-byte sector when it is gathered
-	float pad[3];
-};
+// exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  The per-pixel body is
+// refl_backward_pixel (gsr_refl.hpp), which the tile backward of the surfel rasterizer also runs as its prologue (fused path).
 template <bool RGBA>
 __global__ void __launch_bounds__(256)
 deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
@@ -563,129 +356,29 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
 	const size_t p = live ? pix : 0;
 	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
 	// every load that does not depend on the reflected direction is issued here, with the normal
-	const float nvx = normal_view[p], nvy = normal_view[HW + p], nvz = normal_view[2 * HW + p];
-	const float sv = strength[p];
-	float gfin[3], bas[3], grc[3] = {0.f, 0.f, 0.f}, gnw[3] = {0.f, 0.f, 0.f};
+	ReflBwdIn in;
+	in.nvx = normal_view[p]; in.nvy = normal_view[HW + p]; in.nvz = normal_view[2 * HW + p];
+	in.sv = strength[p];
+	in.has_grc = g_refl_color != nullptr;
+	in.has_gnw = g_nworld != nullptr;
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
-		gfin[c] = g_final[c * HW + p];
-		bas[c] = base[c * HW + p];
-		if (g_refl_color) grc[c] = g_refl_color[c * HW + p];
-		if (g_nworld) gnw[c] = g_nworld[c * HW + p];
+		in.gfin[c] = g_final[c * HW + p];
+		in.bas[c] = base[c * HW + p];
+		in.grc[c] = g_refl_color ? g_refl_color[c * HW + p] : 0.f;
+		in.gnw[c] = g_nworld ? g_nworld[c * HW + p] : 0.f;
 	}
-	ReflPixel o;
-	refl_pixel(cam, nvx, nvy, nvz, px, py, o);
-	const bool fail = (o.rx == 0.f && o.ry == 0.f && o.rz == 0.f);
-	Seamless s;
-	int face = 0;
-	s.kx = 0; s.ky = 0; s.flag = 0; s.is_vertex = false;
-	if (!fail) {
-		float u, v;
-		cube_uv(o.rx, o.ry, o.rz, u, v, face);
-		seamless_index(face, L, u, v, s);
-	}
-	float graw[3] = {0.f, 0.f, 0.f};
-	float gs = 0.f, grx = 0.f, gry = 0.f, grz = 0.f;
-	float cv[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-	if (!fail) fetch_corners<RGBA>(s, L, cubemap, rgba, cv);
-#pragma unroll
-	for (int c = 0; c < 3; c++) {
-		float cval;
-		const float v00 = cv[0][c], v01 = cv[1][c], v10 = cv[2][c], v11 = cv[3][c];
-		if (fail) cval = fail_value[c];
-		else cval = (1 - s.ky) * ((1 - s.kx) * v00 + s.kx * v01) + s.ky * ((1 - s.kx) * v10 + s.kx * v11);
-		const float rc = sigmoidf_(cval);
-		const float gf = gfin[c];
-		const float b = bas[c];
-		if (live) g_base[c * HW + p] = (1 - sv) * gf;
-		gs += gf * (rc - b);
-		float gc = sv * gf;
-		if (g_refl_color) gc += grc[c];
-		graw[c] = gc * rc * (1 - rc);   // sigmoid'
-		if (fail) {
-			if (live) atomicAdd(g_fail + c, graw[c]);
-		} else {
-			float lg0 = (1 - s.ky) * (v01 - v00) + s.ky * (v11 - v10);
-			float lg1 = (1 - s.kx) * (v10 - v00) + s.kx * (v11 - v01);
-			lg0 *= 0.5f * (float)L * graw[c];
-			lg1 *= 0.5f * (float)L * graw[c];
-			if (s.flag & 1) lg0 = -lg0;
-			if (s.flag & 4) lg1 = -lg1;
-			lg1 = -lg1;
-			float a, bb, cc;
-			cube_uv_backward(face, o.rx, o.ry, o.rz, lg0, lg1, a, bb, cc);
-			grx += a; gry += bb; grz += cc;
-		}
-	}
-	// flag == 0 already implies the unclamped 2x2 block; the corner test keeps the record format honest regardless
-	bool interior = !fail && s.flag == 0 && s.x[3] == s.x[0] + 1 && s.y[3] == s.y[0] + 1;
-	// keys_fwd: the forward kernel already wrote the sort keys (same arithmetic on the same inputs) and the sort may be running beside this
-	// kernel.  Its key decides whether the pixel has a record; should the two kernels ever disagree, the pixel goes through the rim
-	// path below and its record, if the sort expects one, is zeros — nothing is lost or read uninitialised.
 	const uint32_t kf = keys_fwd ? keys_fwd[p] : no_key;
-	if (keys_fwd) interior = interior && kf == (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
-	{
-		// rim pixels (~2/L of all, about one per wave): the wave serves them one at a time.  The pixel's corner texels and
-		// weights travel through SGPRs and lanes 0..11 each add one (corner, channel) value, so a rim pixel costs one atomic
-		// instruction whose twelve dwords fall into four 16-byte slots — four memory-side requests instead of twelve
-		// single-lane ones (float atomics are priced per request: 44 us -> 15 us per launch at C3).
-		const int lane = threadIdx.x & 63;
-		const int k_of_lane = lane / 3, c_of_lane = lane - 3 * k_of_lane;
-		// bilinear weights of the four corners (a cube vertex has three, the fourth is their mean)
-		const float extra_g = s.is_vertex ? s.ky * s.kx / 3.f : 0.f;
-		const float w4[4] = {(1 - s.ky) * (1 - s.kx) + extra_g, (1 - s.ky) * s.kx + extra_g, s.ky * (1 - s.kx) + extra_g, s.ky * s.kx};
-		unsigned long long todo = __ballot(live && !fail && !interior);
-		while (todo) {
-			const int src = __ffsll((long long)todo) - 1;
-			todo &= todo - 1;
-			uint32_t tk[4];
-			float wk[4], gk[3];
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int f = __builtin_amdgcn_readlane(s.f[k], src), y = __builtin_amdgcn_readlane(s.y[k], src), x = __builtin_amdgcn_readlane(s.x[k], src);
-				tk[k] = (uint32_t)(((size_t)f * L + y) * L + x);
-				wk[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w4[k]), src));
-			}
-#pragma unroll
-			for (int c = 0; c < 3; c++) gk[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(graw[c]), src));
-			const int corners = __builtin_amdgcn_readlane((int)s.is_vertex, src) ? 3 : 4;
-			if (k_of_lane < corners) {
-				const uint32_t t = k_of_lane == 0 ? tk[0] : k_of_lane == 1 ? tk[1] : k_of_lane == 2 ? tk[2] : tk[3];
-				const float w = k_of_lane == 0 ? wk[0] : k_of_lane == 1 ? wk[1] : k_of_lane == 2 ? wk[2] : wk[3];
-				const float g = c_of_lane == 0 ? gk[0] : c_of_lane == 1 ? gk[1] : gk[2];
-				atomicAdd(g_scratch + ((size_t)t << 2) + c_of_lane, w * g);
-			}
-		}
-	}
+	ReflBwdOut o;
+	refl_backward_pixel<RGBA>(cam, cubemap, rgba, fail_value, L, px, py, live, in, g_fail, g_scratch, footprints + p, keys_fwd != nullptr, kf,
+	                          keys ? keys + p : nullptr, no_key, (int)(threadIdx.x & 63), o);
 	if (!live) return;
-	{
-		const uint32_t t00 = (uint32_t)(((size_t)s.f[0] * L + s.y[0]) * L + s.x[0]);
-		if (interior) {
-			float* f = reinterpret_cast<float*>(footprints + pix);
-			*reinterpret_cast<float4*>(f) = make_float4(graw[0], graw[1], graw[2], s.kx);
-			f[4] = s.ky;
-		} else if (kf != no_key) {
-			float* f = reinterpret_cast<float*>(footprints + pix);
-			*reinterpret_cast<float4*>(f) = make_float4(0.f, 0.f, 0.f, 0.f);
-			f[4] = 0.f;
-		}
-		if (!keys_fwd) keys[pix] = interior ? t00 : no_key;
-	}
-	g_strength[p] = gs;
-	// r = d - 2 n (d.n)  ->  g_n = -2 [ (d.n) g_r + (g_r.n) d ]
-	const float grn = grx * o.nx + gry * o.ny + grz * o.nz;
-	float gnx = -2.f * (o.dn * grx + grn * o.dx);
-	float gny = -2.f * (o.dn * gry + grn * o.dy);
-	float gnz = -2.f * (o.dn * grz + grn * o.dz);
-	if (g_nworld) { gnx += gnw[0]; gny += gnw[1]; gnz += gnw[2]; }
-	const float inv = 1.0f / (o.len + 1e-6f);
-	float gwx = gnx * inv, gwy = gny * inv, gwz = gnz * inv;
-	if (o.len > 0.f) {
-		const float k = (o.nwx * gnx + o.nwy * gny + o.nwz * gnz) * inv * inv / o.len;
-		gwx -= o.nwx * k; gwy -= o.nwy * k; gwz -= o.nwz * k;
-	}
+	g_strength[p] = o.g_strength;
 #pragma unroll
-	for (int c = 0; c < 3; c++) g_normal_view[c * HW + p] = gwx * cam[c] + gwy * cam[3 + c] + gwz * cam[6 + c];
+	for (int c = 0; c < 3; c++) {
+		g_base[c * HW + p] = o.g_base[c];
+		g_normal_view[c * HW + p] = o.g_nv[c];
+	}
 }
 
 // scratch [6][L][L][4] (channel-interleaved) -> grad_cubemap [6][3][L][L] (written, not accumulated)
@@ -836,7 +529,7 @@ extern "C" int gsr_cubemap_backward(const float* grad_outputs, const float* inpu
 	return 0;
 }
 
-extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+extern "C" int gsr_deferred_reflection_forward_keys(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                   const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                   float* out_final, float* out_refl_color, float* out_normal_world, float* cubemap_rgba,
                                                   uint32_t* sort_keys, void* stream_) {
@@ -861,10 +554,17 @@ extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, cons
 	GSR_LAUNCH_CHECK(0, stream);
 	return 0;
 }
+/* the round-2 signature of gsr_deferred_reflection_forward_ex (no sort keys), kept for callers built against the earlier header */
+extern "C" int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                                  const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                                  float* out_final, float* out_refl_color, float* out_normal_world, float* cubemap_rgba, void* stream_) {
+	return gsr_deferred_reflection_forward_keys(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, out_final, out_refl_color,
+	                                            out_normal_world, cubemap_rgba, nullptr, stream_);
+}
 extern "C" int gsr_deferred_reflection_forward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                float* out_final, float* out_refl_color, float* out_normal_world, void* stream_) {
-	return gsr_deferred_reflection_forward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, out_final, out_refl_color,
+	return gsr_deferred_reflection_forward_keys(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, out_final, out_refl_color,
 	                                          out_normal_world, nullptr, nullptr, stream_);
 }
 
@@ -885,7 +585,7 @@ struct ReflScratch {
 #define REFL_SMALL_SORT 1
 #endif
 static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
-                            bool pre_cleared = false, bool small = false) {
+                            bool pre_cleared = false, bool small = false, hipEvent_t gate = nullptr) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
 	if (temp == nullptr) {   // size query: the largest of the drivers' needs (neither the runtime switch nor the stream a tail runs on changes a scratch size)
 		size_t own = 0, pub = 0, sm = 0;
@@ -898,15 +598,18 @@ static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, const uint3
 		if (sm > bytes) bytes = sm;
 		return hipSuccess;
 	}
-	if (!option_sort_driver())   // gsr_set_option("sort_driver", 0) or an unknown rocPRIM release: the public entry point
-		return rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+	if (!option_sort_driver()) {  // gsr_set_option("sort_driver", 0) or an unknown rocPRIM release: the public entry point (the gate then is the sort's end)
+		hipError_t e = rocprim::radix_sort_pairs(temp, bytes, (const uint32_t*)keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, false);
+		if (e == hipSuccess && gate) e = hipEventRecord(gate, stream);
+		return e;
+	}
 	if (small)
-		return onesweep_sort_pairs<256, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+		return onesweep_sort_pairs<256, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 	if (key_bits > 16 && key_bits <= 18)
-		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 	if (key_bits > 18 && key_bits <= 20)
-		return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
-	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared);
+		return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
+	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 }
 static size_t refl_sort_cleared_bytes(int key_bits, size_t n, bool small) {
 	if (small) return onesweep_cleared_bytes<256, 8, 8>(n, 0u, (unsigned)key_bits);
@@ -947,8 +650,10 @@ extern "C" size_t gsr_deferred_reflection_scratch_floats(uint32_t L, int width, 
 namespace {
 struct SideStream {
 	hipStream_t stream = nullptr;
-	hipEvent_t fork = nullptr, fork2 = nullptr, done = nullptr;
+	hipEvent_t fork = nullptr, fork2 = nullptr, done = nullptr, sorted = nullptr, gate = nullptr;
 	bool recorded = false;      // `done` has been recorded at least once (an event that was never recorded must not be waited on)
+	bool sorted_recorded = false;
+	bool gate_pending = false;  // `gate` = "the last pass of the key sort is next on the side stream": the rasterizer's tile backward waits for it ONCE
 };
 std::mutex g_side_mu;
 SideStream g_side[64];
@@ -965,7 +670,8 @@ SideStream* side_stream() {   // (g_side_mu held)
 		if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
 #endif
 		if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.fork2, hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+		    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.sorted, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&s.gate, hipEventDisableTiming) != hipSuccess) {
 			(void)hipStreamDestroy(s.stream);
 			s.stream = nullptr;
 			return nullptr;
@@ -974,6 +680,25 @@ SideStream* side_stream() {   // (g_side_mu held)
 	return &s;
 }
 }  // namespace
+
+// The gate of the key sort (see SideStream::gate_pending): called by the rasterizer backward right before its tile kernel.  A sort pass of
+// 1024-thread workgroups that starts AFTER that kernel has filled the chip waits for the whole 0.7 ms of it (its single-wave workgroups
+// retire one at a time, never sixteen wave slots of a CU at once), the run combine behind it then runs beside the per-Gaussian backward
+// (0.115 -> 0.155 ms) and ends after it; a pass that has started before gets its CUs first (highest stream priority).  So the tile
+// kernel is held back until the LAST pass is next in line — measured: 13 us of hold for 55 us back.
+namespace gsr {
+int side_gate_wait(hipStream_t stream) {
+	std::lock_guard<std::mutex> lk(g_side_mu);
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+	SideStream& s = g_side[dev];
+	if (s.stream && s.gate_pending) {
+		s.gate_pending = false;
+		GSR_HIP_CHECK(hipStreamWaitEvent(stream, s.gate, 0));
+	}
+	return 0;
+}
+}  // namespace gsr
 
 extern "C" int gsr_side_join(void* stream_) {
 	std::lock_guard<std::mutex> lk(g_side_mu);
@@ -986,15 +711,161 @@ extern "C" int gsr_side_join(void* stream_) {
 	return 0;
 }
 
-extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+namespace gsr {
+// ---- host side of the texel-gradient tail, shared by gsr_deferred_reflection_backward* and the fused surfel backward
+// (gsr_surfel_backward_refl, gsr_surfel.hip), whose tile kernel runs the pixel part as its prologue.  Order of use:
+//   refl_tail_begin   carve the scratch, pick the stream of the tail (locks the side stream when async)
+//   [the caller zeroes clear[0..1] on `stream` — refl_tail_clear() does it with two fills — before anything else]
+//   refl_tail_sort    with forward keys: fork the side stream and start the sort (it depends on nothing the pixel code computes)
+//   [the caller's pixel code on `stream`: records, rim atomics into `staging`, fail-value sums into `fail_acc`]
+//   refl_tail_finish  join the pixel code, (sort,) run combine, unpack, `done` event
+int refl_tail_begin(ReflTail& t, uint32_t L, int width, int height, float* scratch, size_t scratch_floats, const uint32_t* sort_keys, int async_tail,
+                    int accumulate, float* g_cubemap, float* g_fail, hipStream_t stream) {
+	const ReflScratch rs = refl_scratch(L, width, height);
+	if (scratch_floats < rs.total_floats || rs.n >= ((size_t)1 << 30) || rs.ntex >= 0xFFFFFFFFull || ((uintptr_t)scratch & 31) != 0) {
+		set_error("reflection backward (sorted footprints): scratch of %zu floats, 32-byte aligned, needed (gsr_deferred_reflection_scratch_floats(L, W, H, 1))",
+		          rs.total_floats);
+		return GSR_E_INVALID;
+	}
+	t.L = L; t.n = rs.n; t.ntex = rs.ntex; t.key_bits = rs.key_bits; t.sort_bytes = rs.sort_bytes;
+	t.staging = scratch;
+	t.fail_acc = scratch + rs.ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
+	ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + (rs.ntex + 1) * 4 + 4);   // 32-byte aligned as long as scratch is
+	t.footprints = fp;
+	t.keys_in = reinterpret_cast<uint32_t*>(fp + rs.n);
+	t.keys_out = t.keys_in + rs.n;
+	t.pix_out = t.keys_out + rs.n;
+	t.sort_temp = reinterpret_cast<void*>(((uintptr_t)(t.pix_out + rs.n) + 255) & ~(uintptr_t)255);
+	t.sort_keys = sort_keys;
+	// sort_keys: the forward already wrote the keys, so the sort depends on nothing the backward computes: with async_tail it forks
+	// BEFORE the pixel code and runs beside it and only the combine waits for the records.  Without keys the sort follows the pixel code and,
+	// on the side stream, has to share the chip with the tile backward: the small shape then (see refl_sort).
+	t.small_sort = async_tail && !sort_keys && REFL_SMALL_SORT;
+	t.clear_ptr[0] = scratch; t.clear_bytes[0] = (rs.ntex + 1) * 4 * sizeof(float);
+	t.clear_ptr[1] = t.sort_temp; t.clear_bytes[1] = refl_sort_cleared_bytes(rs.key_bits, rs.n, t.small_sort);
+	t.stream = stream; t.tail = stream; t.side = nullptr; t.locked = false;
+	t.g_cubemap = g_cubemap; t.g_fail = g_fail; t.accumulate = accumulate;
+	if (async_tail) {
+		g_side_mu.lock();
+		t.locked = true;
+		SideStream* side = side_stream();
+		if (side) { t.side = side; t.tail = side->stream; }
+	}
+	return 0;
+}
+void refl_tail_abort(ReflTail& t) {
+	if (t.locked) { g_side_mu.unlock(); t.locked = false; }
+}
+int refl_tail_clear(ReflTail& t) {
+	hipError_t e = hipMemsetAsync(t.clear_ptr[0], 0, t.clear_bytes[0], t.stream);
+	if (e == hipSuccess) e = hipMemsetAsync(t.clear_ptr[1], 0, t.clear_bytes[1], t.stream);
+	if (e != hipSuccess) { refl_tail_abort(t); set_error("reflection backward: clearing the scratch failed: %s", hipGetErrorString(e)); return GSR_E_HIP; }
+	return 0;
+}
+#define REFL_TAIL_CHECK(expr)                                                                                     \
+	do {                                                                                                          \
+		hipError_t _e = (expr);                                                                                   \
+		if (_e != hipSuccess) {                                                                                   \
+			refl_tail_abort(t);                                                                                   \
+			gsr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);            \
+			return GSR_E_HIP;                                                                                     \
+		}                                                                                                         \
+	} while (0)
+// With forward keys: fork the side stream and start the sort (between the clears and the pixel code).
+int refl_tail_sort(ReflTail& t) {
+	if (!t.sort_keys) return 0;
+	SideStream* side = static_cast<SideStream*>(t.side);
+	if (side) {
+		REFL_TAIL_CHECK(hipEventRecord(side->fork, t.stream));
+		REFL_TAIL_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+	}
+	size_t sb = t.sort_bytes;
+	StageTimer tt(GSR_STAGE_REFL_BWD_TAIL, t.tail);     // timed on the stream it runs on: with async_tail NOT inside GSR_STAGE_REFL_BWD's events
+	REFL_TAIL_CHECK(refl_sort(t.sort_temp, sb, t.key_bits, t.sort_keys, t.keys_out, t.pix_out, t.n, t.tail, true, false, side ? side->gate : nullptr));
+	if (side) side->gate_pending = true;
+	return 0;
+}
+// The sort of the footprint keys, EARLY: called by a forward that has just written the keys (gsr_surfel_forward_refl) with the scratch the
+// backward will use.  async: on the side stream, forked behind the kernel that wrote the keys — it then runs beside whatever the caller
+// enqueues next (the loss; the fills and the pixel kernel of the backward) while the chip still has room: a 1024-thread sort workgroup
+// cannot start on a CU the tile backward has filled (round 3), and since round 4 the backward's pixel kernel is short enough that a sort
+// forked in the backward no longer finished before that kernel took the chip (its second pass then waited 0.8 ms and the run combine ran
+// after the tile backward, beside — and at the expense of — the per-Gaussian backward).  The backward is told with keys_sorted = 1.
+int refl_sort_keys_early(uint32_t L, int width, int height, float* scratch, size_t scratch_floats, const uint32_t* sort_keys, int async, hipStream_t stream) {
+	ReflTail t;
+	int rc = refl_tail_begin(t, L, width, height, scratch, scratch_floats, sort_keys, async, 0, nullptr, nullptr, stream);
+	if (rc < 0) return rc;
+	SideStream* side = static_cast<SideStream*>(t.side);
+	if (side) {
+		REFL_TAIL_CHECK(hipEventRecord(side->fork, t.stream));
+		REFL_TAIL_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+	}
+	{
+		StageTimer tt(GSR_STAGE_REFL_BWD_TAIL, t.tail);
+		REFL_TAIL_CHECK(hipMemsetAsync(t.clear_ptr[1], 0, t.clear_bytes[1], t.tail));
+		size_t sb = t.sort_bytes;
+		REFL_TAIL_CHECK(refl_sort(t.sort_temp, sb, t.key_bits, t.sort_keys, t.keys_out, t.pix_out, t.n, t.tail, true, false, side ? side->gate : nullptr));
+	}
+	if (side) {
+		side->gate_pending = true;
+		REFL_TAIL_CHECK(hipEventRecord(side->sorted, side->stream));
+		side->sorted_recorded = true;
+	}
+	refl_tail_abort(t);
+	return 0;
+}
+// keys_sorted: the backward's counterpart — the stream its tail runs on is ordered behind the early sort (a no-op when that is the side
+// stream itself: the combine is enqueued there behind the sort anyway)
+int refl_tail_join_early_sort(ReflTail& t) {
+	std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
+	if (!t.locked) lk.lock();
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+	SideStream& s = g_side[dev];
+	if (s.stream && s.sorted_recorded && t.tail != s.stream) REFL_TAIL_CHECK(hipStreamWaitEvent(t.tail, s.sorted, 0));
+	return 0;
+}
+
+int refl_tail_finish(ReflTail& t) {
+	SideStream* side = static_cast<SideStream*>(t.side);
+	if (side) {     // the combine needs the records (and, without forward keys, the sort needs the keys) the pixel code just wrote
+		hipEvent_t ev = t.sort_keys ? side->fork2 : side->fork;
+		REFL_TAIL_CHECK(hipEventRecord(ev, t.stream));
+		REFL_TAIL_CHECK(hipStreamWaitEvent(side->stream, ev, 0));
+	}
+	{
+		StageTimer tt(GSR_STAGE_REFL_BWD_TAIL, t.tail);
+		const size_t per_wg = (size_t)256 * REFL_CHUNK;
+		const unsigned cgrid = (unsigned)((t.n + per_wg - 1) / per_wg);
+		const ReflFootprint* fp = static_cast<const ReflFootprint*>(t.footprints);
+		if (!t.sort_keys) {
+			size_t sb = t.sort_bytes;
+			REFL_TAIL_CHECK(refl_sort(t.sort_temp, sb, t.key_bits, t.keys_in, t.keys_out, t.pix_out, t.n, t.tail, true, t.small_sort));
+		}
+		refl_run_combine_kernel<<<cgrid, 256, 0, t.tail>>>(t.keys_out, t.pix_out, fp, t.n, t.L, (uint32_t)t.ntex, t.staging);
+		auto unpack = t.accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
+		unpack<<<(unsigned)((t.ntex + 255) / 256), 256, 0, t.tail>>>((const float4*)t.staging, t.g_cubemap, t.g_fail, (int)t.L);
+	}
+	if (side) {
+		REFL_TAIL_CHECK(hipEventRecord(side->done, side->stream));
+		side->recorded = true;
+	}
+	REFL_TAIL_CHECK(hipGetLastError());
+	refl_tail_abort(t);      // (releases the side-stream lock)
+	return 0;
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_deferred_reflection_backward_keys(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
                                                    const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
                                                    const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                    float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
                                                    float* scratch, size_t scratch_floats, int accumulate, int async_tail, const float* cubemap_rgba,
-                                                   const uint32_t* sort_keys, void* stream_) {
+                                                   const uint32_t* sort_keys, int keys_sorted, void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (width <= 0 || height <= 0 || !normal_view || !base_color || !refl_strength || !cam || !cubemap || !fail_value || !g_final ||
-	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0) {
+	    !g_normal_view || !g_base || !g_strength || !g_cubemap || !g_fail || !scratch || L == 0 || (keys_sorted && !sort_keys)) {
 		set_error("gsr_deferred_reflection_backward: invalid argument");
 		return GSR_E_INVALID;
 	}
@@ -1002,89 +873,68 @@ extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, con
 	const ReflScratch rs = refl_scratch(L, width, height);
 	const size_t ntex = rs.ntex;
 	if (scratch_floats < (ntex + 1) * 4) { set_error("gsr_deferred_reflection_backward: scratch smaller than (6*L*L+1)*4 floats"); return GSR_E_INVALID; }
-	float* fail_acc = scratch + ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
 	const bool binned = scratch_floats >= rs.total_floats && rs.n < ((size_t)1 << 30) && rs.ntex < 0xFFFFFFFFull && ((uintptr_t)scratch & 31) == 0;
-	GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, (ntex + 1) * 4 * sizeof(float), stream));
-	auto st_ = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD, stream);      // the pixel kernel; the texel-gradient tail is GSR_STAGE_REFL_BWD_TAIL
-	const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
+	if (keys_sorted && !binned) { set_error("gsr_deferred_reflection_backward: keys_sorted needs the scratch the forward sorted into"); return GSR_E_INVALID; }
 	if (!binned) {
 		// texel gradients by float atomics straight from the pixel kernel (memory-side, ~2.5 requests per pixel)
-		deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
-		                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, fail_acc);
-	} else {
-		// sorted footprints: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
-		// (texel id, pixel) makes equal texels adjacent; refl_run_combine_kernel gathers the records in that order, sums runs in
-		// registers and a workgroup's texel range in LDS.
-		ReflFootprint* fp = reinterpret_cast<ReflFootprint*>(scratch + (ntex + 1) * 4 + 4);   // 32-byte aligned as long as scratch is
-		uint32_t* keys_in = reinterpret_cast<uint32_t*>(fp + rs.n);
-		uint32_t* keys_out = keys_in + rs.n;
-		uint32_t* pix_out = keys_out + rs.n;
-		void* sort_temp = reinterpret_cast<void*>(((uintptr_t)(pix_out + rs.n) + 255) & ~(uintptr_t)255);
-		const unsigned egrid = (unsigned)((HW + 255) / 256);
-		// sort_keys: the forward already wrote the keys (gsr_deferred_reflection_forward_ex), so the sort depends on nothing this call
-		// computes: with async_tail it forks BEFORE the pixel kernel and runs beside it (an HBM- and latency-bound kernel without LDS: the
-		// 1024-thread passes find room at once) and only the combine waits for the records.  Without them the sort follows the pixel
-		// kernel and, on the side stream, has to share the chip with the tile backward: the small shape then (see refl_sort).
-		const bool small_sort = async_tail && !sort_keys && REFL_SMALL_SORT;
-		const size_t clr = refl_sort_cleared_bytes(rs.key_bits, rs.n, small_sort);
-		hipStream_t tail = stream;
-		SideStream* side = nullptr;
-		std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
-		if (async_tail) {
-			lk.lock();
-			side = side_stream();
-			if (side) tail = side->stream;
-		}
-		size_t sb = rs.sort_bytes;
-		std::unique_ptr<StageTimer> tail_timer;     // GSR_STAGE_REFL_BWD_TAIL is timed on the stream it runs on: with async_tail NOT inside GSR_STAGE_REFL_BWD's events
-		if (sort_keys) {
-			if (side) {
-				GSR_HIP_CHECK(hipEventRecord(side->fork, stream));
-				GSR_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-			}
-			tail_timer = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD_TAIL, tail);
-			GSR_HIP_CHECK(hipMemsetAsync(sort_temp, 0, clr, tail));
-			GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, sort_keys, keys_out, pix_out, rs.n, tail, true, false));
-		}
-		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
-			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
-			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
-			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc, scratch, fp,
-			                                                                 keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : sort_temp, sort_keys ? 0 : clr);
-		else
-			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
-			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, fail_acc,
-			                                                                  scratch, fp, keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : sort_temp,
-			                                                                  sort_keys ? 0 : clr);
-		// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
-		st_.reset();
-		if (side) {     // the combine needs the records (and, without forward keys, the sort needs the keys) the pixel kernel just wrote
-			hipEvent_t ev = sort_keys ? side->fork2 : side->fork;
-			GSR_HIP_CHECK(hipEventRecord(ev, stream));
-			GSR_HIP_CHECK(hipStreamWaitEvent(side->stream, ev, 0));
-		}
-		if (!sort_keys) {
-			tail_timer = std::make_unique<StageTimer>(GSR_STAGE_REFL_BWD_TAIL, tail);
-			GSR_HIP_CHECK(refl_sort(sort_temp, sb, rs.key_bits, keys_in, keys_out, pix_out, rs.n, tail, true, small_sort));
-		}
+		float* fail_acc = scratch + ntex * 4;   // [texel staging ntex*4][fail-value gradient 4]
+		GSR_HIP_CHECK(hipMemsetAsync(scratch, 0, (ntex + 1) * 4 * sizeof(float), stream));
 		{
-		const size_t per_wg = (size_t)256 * REFL_CHUNK;
-		refl_run_combine_kernel<<<(unsigned)((rs.n + per_wg - 1) / per_wg), 256, 0, tail>>>(keys_out, pix_out, fp, rs.n, L, (uint32_t)ntex, scratch);
+			StageTimer st_(GSR_STAGE_REFL_BWD, stream);
+			const unsigned grid = (unsigned)((HW * 4 + 255) / 256);
+			deferred_refl_bwd_kernel<<<grid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, fail_value, (int)L, width, height, g_final,
+			                                                  g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, scratch, fail_acc);
+		}
 		auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
-		unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, tail>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
-		}
-		tail_timer.reset();
-		if (side) {
-			GSR_HIP_CHECK(hipEventRecord(side->done, side->stream));
-			side->recorded = true;
-		}
+		unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
 		GSR_LAUNCH_CHECK(0, stream);
 		return 0;
 	}
-	auto unpack = accumulate ? unpack_cubemap_grad_kernel<true> : unpack_cubemap_grad_kernel<false>;
-	unpack<<<(unsigned)((ntex + 255) / 256), 256, 0, stream>>>((const float4*)scratch, g_cubemap, g_fail, (int)L);
-	GSR_LAUNCH_CHECK(0, stream);
-	return 0;
+	// sorted footprints: the pixel kernel stores one footprint record per pixel and its texel id as a sort key; a radix sort of
+	// (texel id, pixel) makes equal texels adjacent; refl_run_combine_kernel gathers the records in that order, sums runs in
+	// registers and a workgroup's texel range in LDS.
+	ReflTail t;
+	int rc = refl_tail_begin(t, L, width, height, scratch, scratch_floats, sort_keys, async_tail, accumulate, g_cubemap, g_fail, stream);
+	if (rc < 0) return rc;
+	// the staging buffer is zeroed here; the sort's look-back state by the pixel kernel (no forward keys: the sort follows it) or by a fill
+	// in front of the sort (forward keys); keys_sorted: the forward call has sorted (or is still sorting, on the side stream) into this
+	// scratch: only the staging buffer is touched
+	if (sort_keys && !keys_sorted) rc = refl_tail_clear(t);
+	else if (hipMemsetAsync(t.clear_ptr[0], 0, t.clear_bytes[0], stream) != hipSuccess) { refl_tail_abort(t); set_error("hipMemsetAsync failed"); return GSR_E_HIP; }
+	if (rc < 0) return rc;
+	rc = keys_sorted ? refl_tail_join_early_sort(t) : refl_tail_sort(t);
+	if (rc < 0) return rc;
+	{
+		StageTimer st_(GSR_STAGE_REFL_BWD, stream);      // the pixel kernel; the texel-gradient tail is GSR_STAGE_REFL_BWD_TAIL
+		const unsigned egrid = (unsigned)((HW + 255) / 256);
+		ReflFootprint* fp = static_cast<ReflFootprint*>(t.footprints);
+		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
+			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
+			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
+			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, t.fail_acc, t.staging, fp,
+			                                                                 t.keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : t.sort_temp,
+			                                                                 sort_keys ? 0 : t.clear_bytes[1]);
+		else
+			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
+			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, t.fail_acc,
+			                                                                  t.staging, fp, t.keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : t.sort_temp,
+			                                                                  sort_keys ? 0 : t.clear_bytes[1]);
+	}
+	// the per-pixel gradients are complete here; what follows only produces dL_dcubemap / dL_dfail
+	return refl_tail_finish(t);
+}
+
+/* the round-2 signature of gsr_deferred_reflection_backward_ex (no forward keys): kept so that a caller built against the earlier header
+ * keeps working; gsr_deferred_reflection_backward_keys is the full form */
+extern "C" int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
+                                                   const float* cubemap, const float* fail_value, uint32_t L, int width, int height,
+                                                   const float* g_final, const float* g_refl_color, const float* g_normal_world,
+                                                   float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
+                                                   float* scratch, size_t scratch_floats, int accumulate, int async_tail, const float* cubemap_rgba,
+                                                   void* stream_) {
+	return gsr_deferred_reflection_backward_keys(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
+	                                             g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate,
+	                                             async_tail, cubemap_rgba, nullptr, 0, stream_);
 }
 
 extern "C" int gsr_deferred_reflection_backward_accum(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,
@@ -1092,9 +942,9 @@ extern "C" int gsr_deferred_reflection_backward_accum(const float* normal_view, 
                                                 const float* g_final, const float* g_refl_color, const float* g_normal_world,
                                                 float* g_normal_view, float* g_base, float* g_strength, float* g_cubemap, float* g_fail,
                                                 float* scratch, size_t scratch_floats, int accumulate, void* stream_) {
-	return gsr_deferred_reflection_backward_ex(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
-	                                           g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate, 0, nullptr,
-	                                           nullptr, stream_);
+	return gsr_deferred_reflection_backward_keys(normal_view, base_color, refl_strength, cam, cubemap, fail_value, L, width, height, g_final, g_refl_color,
+	                                             g_normal_world, g_normal_view, g_base, g_strength, g_cubemap, g_fail, scratch, scratch_floats, accumulate, 0, nullptr,
+	                                             nullptr, 0, stream_);
 }
 
 extern "C" int gsr_deferred_reflection_backward(const float* normal_view, const float* base_color, const float* refl_strength, const float* cam,

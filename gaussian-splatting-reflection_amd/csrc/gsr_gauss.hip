@@ -522,6 +522,10 @@ gauss_render_bwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* _
 // computeCov2DCUDA + preprocessCUDA backward + computeCov3D backward fused into one per-Gaussian pass
 // (DGR backward.cu:147-326, 330-393, 399-449).  Every output element is written (zeros for culled
 // Gaussians), so the caller does not need the reference's 11 zero-filled tensors.
+// ACC (round 4, as surfel_preprocess_bwd_kernel): the PARAMETER gradients (mean3D, sh, opacity, scale, rotation, normal, refl strength) are
+// ADDED to the output tensors instead of written — several views accumulate into one gradient buffer on the device
+// (gsr_gauss_backward_accum); the per-view outputs (dL_dmean2D_pixels, dL_dcolor, dL_dcov3D, the intermediates) are written either way.
+template <bool ACC>
 __global__ void __launch_bounds__(256)
 gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
                             const uint8_t* __restrict__ clamped, const float* __restrict__ opacities, const float* __restrict__ scales,
@@ -544,7 +548,7 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 	const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
 	// pass-through outputs of the tile kernel
 	if (in_range) {
-		dL_drefl[idx] = a1.z;
+		put<ACC>(dL_drefl + idx, a1.z);
 		if (has_invdepth) dL_dinvdepth[idx] = a1.w;
 		if (dL_dconic != nullptr) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(a3.x, a3.y, 0.f, a3.z);
 	}
@@ -553,7 +557,7 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 		// (outputs the caller did not ask for — NULL — are not written: the tile kernel's intermediate dL_dmean2D / dL_dconic, which the
 		// reference's binding never returns, and the gradients of inputs that were not supplied)
 		if (dL_dcolor != nullptr) wave_store_rows<3, false>(tile, c3, dL_dcolor + (size_t)g0 * 3, nrows, lane);
-		wave_store_rows<3, false>(tile, n3, dL_dnormals + (size_t)g0 * 3, nrows, lane);
+		wave_store_rows<3, ACC>(tile, n3, dL_dnormals + (size_t)g0 * 3, nrows, lane);
 		if (dL_dmean2D != nullptr) wave_store_rows<3, false>(tile, m3, dL_dmean2D + (size_t)g0 * 3, nrows, lane);
 		wave_store_rows<3, false>(tile, p3, dL_dmean2D_pixels + (size_t)g0 * 3, nrows, lane);
 	}
@@ -682,7 +686,7 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 			drot[3] = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
 		}
 	}
-	if (in_range) dL_dopacity[idx] = dL_dopac;
+	if (in_range) put<ACC>(dL_dopacity + idx, dL_dopac);
 	// ---- SH backward (also writes the dL_dsh row, zeros when not visible)
 	if (shs != nullptr) {
 		if (M == 16) {
@@ -705,25 +709,25 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 #pragma unroll
 			for (int t = 0; t < 3; t++) {
 				const float4 q4[4] = {sh_row_f4(4 * t, w, grgb), sh_row_f4(4 * t + 1, w, grgb), sh_row_f4(4 * t + 2, w, grgb), sh_row_f4(4 * t + 3, w, grgb)};
-				wave_store_rows4<4, false>(reinterpret_cast<float4*>(tile), q4, sh_out, 12, 4 * t, nrows, lane);
+				wave_store_rows4<4, ACC>(reinterpret_cast<float4*>(tile), q4, sh_out, 12, 4 * t, nrows, lane);
 			}
 		} else if (in_range) {
 			if (visible) {
 				ShRow s;
 				load_sh(shs, idx, M, (D + 1) * (D + 1), s);
 				const F3 dir = f3(mx - cam.campos[0], my - cam.campos[1], mz - cam.campos[2]);
-				const F3 dm = sh_backward(idx, D, M, s, dir, clamped[idx], f3(a0.x, a0.y, a0.z), dL_dsh);
+				const F3 dm = sh_backward<ACC>(idx, D, M, s, dir, clamped[idx], f3(a0.x, a0.y, a0.z), dL_dsh);
 				dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
-			} else {
+			} else if (!ACC) {
 				float* out = dL_dsh + (size_t)idx * M * 3;
 				for (int q = 0; q < M * 3; q++) out[q] = 0.f;
 			}
 		}
 	}
-	wave_store_rows<3, false>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
+	wave_store_rows<3, ACC>(tile, dmean, dL_dmean3D + (size_t)g0 * 3, nrows, lane);
 	if (dL_dcov3D != nullptr) wave_store_rows<6, false>(tile, dcov, dL_dcov3D + (size_t)g0 * 6, nrows, lane);
-	wave_store_rows<3, false>(tile, dscale, dL_dscale + (size_t)g0 * 3, nrows, lane);
-	if (in_range) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	wave_store_rows<3, ACC>(tile, dscale, dL_dscale + (size_t)g0 * 3, nrows, lane);
+	if (in_range) put4<ACC>(reinterpret_cast<float4*>(dL_drot) + idx, drot[0], drot[1], drot[2], drot[3]);
 }
 
 }  // namespace gsr
@@ -805,7 +809,7 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 	return R;
 }
 
-extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+extern "C" int gsr_gauss_backward_accum(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                   const float* shs, const float* colors_precomp, const float* normals, const float* refl_strengths,
                                   const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
@@ -813,7 +817,7 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
                                   const float* dL_dpix, const float* dL_dnormal_map, const float* dL_drefl_strength_map,
                                   const float* dL_invdepths, float* dL_dmean2D, float* dL_dmean2D_pixels, float* dL_dconic, float* dL_dopacity,
                                   float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth, float* dL_dmean3D,
-                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing, int debug, void* stream_) {
+                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing, int accumulate, int debug, void* stream_) {
 	(void)colors_precomp; (void)normals; (void)refl_strengths;
 	hipStream_t stream = (hipStream_t)stream_;
 	if (P < 0 || R < 0 || width <= 0 || height <= 0) { set_error("gsr_gauss_backward: invalid size"); return GSR_E_INVALID; }
@@ -853,11 +857,29 @@ extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* backg
 	}
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
 	const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : geom.aux;
-{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream); 	gauss_preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,
+{ StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream);
+	auto kern = accumulate ? gauss_preprocess_bwd_kernel<true> : gauss_preprocess_bwd_kernel<false>;
+	kern<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,
 	                                                                 scale_modifier, cov3D_ptr, cam, geom.acc, dL_invdepths ? 1 : 0, antialiasing,
 	                                                                 dL_dmean2D, dL_dmean2D_pixels, dL_dconic, dL_dopacity, dL_dcolor, dL_dnormals,
 	                                                                 dL_drefl_strengths, dL_dinvdepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
 	                                                                 dL_drot); }
 	GSR_LAUNCH_CHECK(debug, stream);
 	return 0;
+}
+
+extern "C" int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* normals, const float* refl_strengths,
+                                  const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                  float tan_fovx, float tan_fovy, const int* radii, void* geom_buffer, void* binning_buffer, void* image_buffer,
+                                  const float* dL_dpix, const float* dL_dnormal_map, const float* dL_drefl_strength_map,
+                                  const float* dL_invdepths, float* dL_dmean2D, float* dL_dmean2D_pixels, float* dL_dconic, float* dL_dopacity,
+                                  float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth, float* dL_dmean3D,
+                                  float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int antialiasing, int debug, void* stream_) {
+	return gsr_gauss_backward_accum(P, D, M, R, background, width, height, means3D, shs, colors_precomp, normals, refl_strengths, opacities, scales,
+	                                scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer,
+	                                binning_buffer, image_buffer, dL_dpix, dL_dnormal_map, dL_drefl_strength_map, dL_invdepths, dL_dmean2D,
+	                                dL_dmean2D_pixels, dL_dconic, dL_dopacity, dL_dcolor, dL_dnormals, dL_drefl_strengths, dL_dinvdepth, dL_dmean3D,
+	                                dL_dcov3D, dL_dsh, dL_dscale, dL_drot, antialiasing, 0, debug, stream_);
 }

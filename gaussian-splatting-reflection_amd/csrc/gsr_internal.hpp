@@ -87,9 +87,10 @@ struct GeomState {
 	int* flags;              // 4 ints: [0] prefiltered-trap flag, [2,3] num_rendered (64 bits): zeroed by the preprocess kernel, accumulated by
 	                         //         gaussian_stats_kernel
 	uint32_t* depth_sorted;  // P        depth bits in ascending order (output of the depth pre-sort; keys only)
-	uint32_t* order;         // P        Gaussian index at each position of the depth order (stable: ties by index)
-	unsigned long long* emit_state;   // one word per 256 Gaussians: decoupled look-back state of emit_tiles_kernel's scan of the instance counts
-	size_t emit_state_bytes;          //   (multiple of 16; zeroed by the preprocess kernel)
+	unsigned long long* order;   // P    at each position of the depth order (stable: ties by index): Gaussian index (low word) and its tile
+	                         //          rectangle packed to 4 x 8 bits (high word; 0 on grids beyond 255 tiles per axis) — OrderRect in gsr_common.hip
+	unsigned long long* emit_state;   // one word per 256 Gaussians: decoupled look-back state of emit_tiles_kernel's scan of the instance counts;
+	size_t emit_state_bytes;          //   the LAST word is the scan's ticket counter (multiple of 16; zeroed by the preprocess kernel)
 	void* scan_temp;         // temp of the two scans (shared) followed by the temp of the P-sized depth sort
 	size_t scan_temp_bytes;
 	void* depth_sort_temp;   // = scan_temp + scan part; its first depth_sort_clear bytes are zeroed by the preprocess kernel (they start with
@@ -132,6 +133,35 @@ uint32_t higher_msb(uint32_t n);
 // -> key/value emission -> radix sort -> tile ranges.  Returns num_rendered or <0.
 int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int tiles_y, const GeomState& geom,
                 const ImageState& img, BinningState* out_binning, int prefiltered, int debug, hipStream_t stream);
+
+// Texel-gradient tail of the deferred-reflection backward (sort of the per-pixel footprint records by texel, run combine, unpack:
+// gsr_cubemap.hip) around the pixel kernel of gsr_deferred_reflection_backward*.  See refl_tail_begin in gsr_cubemap.hip.
+struct ReflTail {
+	float* staging;          // [6][L][L][4] channel-interleaved texel gradients (rim pixels add here directly; the combine adds the rest)
+	float* fail_acc;         // 4 floats behind it: gradient of the fail value
+	void* footprints;        // ReflFootprint[n], one 32-byte record per pixel
+	uint32_t *keys_in, *keys_out, *pix_out;
+	void* sort_temp;
+	void* clear_ptr[2];      // what must be zero before the pixel code runs: [0] staging + fail_acc, [1] the sort's look-back state
+	size_t clear_bytes[2];
+	size_t n, ntex, sort_bytes;
+	int key_bits;
+	uint32_t L;
+	const uint32_t* sort_keys;   // keys written by the forward, or NULL (then the pixel code writes keys_in)
+	bool small_sort, locked;
+	hipStream_t stream, tail;
+	void* side;
+	float *g_cubemap, *g_fail;
+	int accumulate;
+};
+int refl_tail_begin(ReflTail& t, uint32_t L, int width, int height, float* scratch, size_t scratch_floats, const uint32_t* sort_keys, int async_tail,
+                    int accumulate, float* g_cubemap, float* g_fail, hipStream_t stream);
+int refl_tail_clear(ReflTail& t);
+int refl_tail_sort(ReflTail& t);
+int refl_tail_finish(ReflTail& t);
+void refl_tail_abort(ReflTail& t);
+int side_gate_wait(hipStream_t stream);
+int refl_sort_keys_early(uint32_t L, int width, int height, float* scratch, size_t scratch_floats, const uint32_t* sort_keys, int async, hipStream_t stream);
 
 }  // namespace gsr
 
@@ -275,6 +305,21 @@ __device__ __forceinline__ void wave_store_rows4(float4* lds, const float4* v, f
 		}
 	}
 	wave_lds_sync();
+}
+// one element of a per-Gaussian parameter gradient: written, or (ACC: several views accumulate into one gradient buffer on the device) added
+template <bool ACC> __device__ __forceinline__ void put(float* p, float v) {
+	if (ACC) { if (v != 0.f) *p += v; }     // (a view adds nothing to the Gaussians it did not touch: no read, no write)
+	else *p = v;
+}
+template <bool ACC> __device__ __forceinline__ void put4(float4* p, float a, float b, float c, float d) {
+	if (ACC) {
+		if (a != 0.f || b != 0.f || c != 0.f || d != 0.f) {
+			const float4 r = *p;
+			*p = make_float4(r.x + a, r.y + b, r.z + c, r.w + d);
+		}
+	} else {
+		*p = make_float4(a, b, c, d);
+	}
 }
 // v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0 (which __builtin_ctz leaves undefined)
 __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) {

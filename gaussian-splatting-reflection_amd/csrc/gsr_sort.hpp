@@ -1,4 +1,4 @@
-// Onesweep radix sort of (uint32 key, 4-byte value) pairs with ONE clear per sort.
+// Onesweep radix sort of (uint32 key, 4- or 8-byte value) pairs with ONE clear per sort.
 //
 // rocPRIM's radix_sort_pairs issues, per digit pass, a memset of the decoupled look-back states and a memset of the ordered
 // block-id counter (gfx950 takes the atomic block-id path) in front of the pass kernel, plus one memset for the digit
@@ -109,8 +109,9 @@ __device__ __forceinline__ void sort_clear_region(void* ptr, size_t bytes, size_
 // statistics kernel for the depth keys, key emission for the tile ids): no histogram dispatch.
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
 hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, ValuesIn values_in, Value* values_out, size_t size_,
-                               unsigned begin_bit, unsigned end_bit, hipStream_t stream, bool pre_cleared = false, const SortOffset* ext_counts = nullptr) {
-	static_assert(sizeof(Value) == 4, "4-byte values");
+                               unsigned begin_bit, unsigned end_bit, hipStream_t stream, bool pre_cleared = false, const SortOffset* ext_counts = nullptr,
+                               hipEvent_t before_last_pass = nullptr) {
+	static_assert(sizeof(Value) == 4 || sizeof(Value) == 8, "4- or 8-byte values");
 	constexpr unsigned radix = 1u << BITS, items_per_block = BS * IPT;
 	if (size_ >= ((size_t)1 << 30) || end_bit <= begin_bit) return hipErrorInvalidValue;
 	const unsigned size = (unsigned)size_;
@@ -127,7 +128,7 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 	const size_t cleared = o_ids + up((size_t)places * 64);   // one counter per 64 bytes
 	const size_t o_keys_tmp = cleared;
 	const size_t o_vals_tmp = o_keys_tmp + up((size_t)size * 4);
-	const size_t total = o_vals_tmp + up((size_t)size * 4);
+	const size_t total = o_vals_tmp + up((size_t)size * sizeof(Value));
 	if (temp == nullptr) { bytes = total; return hipSuccess; }
 	if (bytes < total) return hipErrorInvalidValue;
 	if (size == 0) return hipSuccess;
@@ -156,6 +157,10 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 		const SortOffset* d_in = counts + (size_t)place * radix;
 		uint32_t* k_out = to_output ? keys_out : keys_tmp;
 		Value* v_out = to_output ? values_out : values_tmp;
+		if (before_last_pass != nullptr && place + 1 == places) {     // (a caller that must not let another kernel take the chip before the LAST pass has started)
+			hipError_t e = hipEventRecord(before_last_pass, stream);
+			if (e != hipSuccess) return e;
+		}
 		if (from_input) {
 			sort_pass_kernel<BS, IPT, BITS, ValuesIn, Value><<<blocks, BS, 0, stream>>>(keys_in, k_out, values_in, v_out, size, d_in, next, lookback, bit,
 			                                                                            current_bits, full_blocks, block_id);
@@ -176,7 +181,7 @@ size_t onesweep_cleared_bytes(size_t, unsigned, unsigned) { return 0; }
 __device__ __forceinline__ void sort_clear_region(void*, size_t, size_t, size_t) {}
 template <unsigned BS, unsigned IPT, unsigned BITS, class ValuesIn, class Value>
 hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t*, uint32_t*, ValuesIn, Value*, size_t, unsigned, unsigned, hipStream_t, bool = false,
-                               const unsigned* = nullptr) {
+                               const unsigned* = nullptr, hipEvent_t = nullptr) {
 	if (temp == nullptr) bytes = 0;
 	return hipErrorNotSupported;
 }

@@ -9,6 +9,7 @@
 #include "gsr_internal.hpp"
 #include "gsr_sort.hpp"
 #include "gsr_math.hpp"
+#include "gsr_refl.hpp"
 
 namespace gsr {
 
@@ -234,13 +235,26 @@ surfel_preprocess_one(int idx, int D, int M, const float* __restrict__ means, co
 // kernel's ~420 write requests per wave (TCP_TCC_WRITE_REQ, profiles/r02_pmc_memory_side_before_coalesced_stores.txt), every one of them a partial
 // line.  Instead each wave transposes its 64 x 7 float4 through LDS and writes 5 + 2 KB of contiguous memory.
 #define S_OUT_F4 7
+// Fused rasterize + reflect path: the texel-interleaved copy [6][L][L] of float4 of the cubemap that the tile kernels' reflection code
+// gathers from (one 16-byte load per bilinear corner, gsr_refl.hpp) is made here, by the first kernel of the forward, instead of by a
+// dispatch of its own in front of the pixel pass (cubemap_interleave_kernel, 5 us).  ntex = 0: nothing to do.
+struct CubemapInterleave {
+	const float* cubemap;
+	float4* rgba;
+	uint32_t ntex, LL;
+};
 __global__ void __launch_bounds__(256)
 surfel_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, const float* __restrict__ scales, float scale_modifier,
                          const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
                          const float* __restrict__ transMat_precomp, const float* __restrict__ colors_precomp,
                          const float* __restrict__ refl, const uint8_t* __restrict__ env_scope_mask, SurfelCam cam, int* __restrict__ radii,
-                         GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights) {
+                         GeomState g, int gx, int gy, int prefiltered, float* __restrict__ gaussian_weights, CubemapInterleave ci) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	for (uint32_t t = (uint32_t)idx; t < ci.ntex; t += gridDim.x * 256u) {
+		const uint32_t f = t / ci.LL, r = t - f * ci.LL;
+		const float* c = ci.cubemap + (size_t)f * 3 * ci.LL + r;
+		ci.rgba[t] = make_float4(c[0], c[ci.LL], c[2 * (size_t)ci.LL], 0.f);
+	}
 	// look-back state of the depth sort that follows (gsr_sort.hpp): cleared here instead of by a dispatch of its own
 	sort_clear_region(g.depth_sort_temp, g.depth_sort_clear, (size_t)idx, (size_t)gridDim.x * 256u);
 	sort_clear_region(g.emit_state, g.emit_state_bytes, (size_t)idx, (size_t)gridDim.x * 256u);   // look-back state of emit_tiles_kernel's scan
@@ -394,12 +408,30 @@ __device__ __forceinline__ lmask surfel_fwd_pair(const SurfelRec& R, const v2f p
 	return ok;
 }
 
+// Arguments of the deferred-reflection epilogue of the forward tile kernel (fused rasterize + reflect path, REFL = true): a wave that has
+// finished its 8x8 pixel block holds the blended view-space normal, the base colour and the reflection strength of its pixels in
+// registers and runs refl_forward_pixel (gsr_refl.hpp: the body of deferred_refl_fwd_kernel) on them before it retires.  The pixel pass
+// of its own read those seven planes back (28 B per pixel) in a 40-us HBM-bound kernel; here its ~150 instructions per pixel disappear in a
+// VALU-bound kernel of 290 M wave-instructions (+ 5 M) and its four 16-byte texel gathers hide behind the other waves' arithmetic.
+struct SurfelReflFwd {
+	const float* cam;
+	const float* cubemap;
+	const float4* rgba;
+	const float* fail_value;
+	int L;
+	uint32_t no_key;
+	float* out_final;
+	float* out_refl_color;
+	float* out_nworld;
+	uint32_t* sort_keys;
+};
+template <bool REFL>
 __global__ void __launch_bounds__(64) GSR_FWD_ATTR
 surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ point_list, int W, int H, int tiles_x, int ntiles,
                               const float4* __restrict__ rec, const float4* __restrict__ bbox, int cull, const float* __restrict__ bg,
                               float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                               float* __restrict__ out_others, float* __restrict__ out_refl, float* __restrict__ gaussian_weights,
-                              unsigned long long* __restrict__ blend_mask, size_t mask_stride) {
+                              unsigned long long* __restrict__ blend_mask, size_t mask_stride, SurfelReflFwd rf) {
 	const uint32_t slot = xcd_slot(blockIdx.x);   // dispatch slot -> (tile, quadrant), longest lists first
 	if (slot >= (uint32_t)ntiles * 4u) return;
 	const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_order[slot >> 2]), quad = slot & 3u;   // (readfirstlane: the compiler cannot see that the loaded tile id is wave-uniform)
@@ -535,10 +567,24 @@ surfel_render_fwd_wave_kernel(const uint2* __restrict__ ranges, const uint32_t* 
 		// the reference converts the float -1 of "no median" with cvt.rzi.u32.f32, which saturates to 0; in C++ that
 		// conversion is undefined (and clang does exploit it), so the clamp is explicit
 		n_contrib[HW + p] = (uint32_t)fmaxf(st.median_contributor, 0.0f);
-		out_color[p] = st.Crg.x + T * bg[0];
-		out_color[HW + p] = st.Crg.y + T * bg[1];
-		out_color[2 * HW + p] = st.C2 + T * bg[2];
+		const float c0 = st.Crg.x + T * bg[0], c1 = st.Crg.y + T * bg[1], c2 = st.C2 + T * bg[2];
+		out_color[p] = c0;
+		out_color[HW + p] = c1;
+		out_color[2 * HW + p] = c2;
 		out_refl[p] = st.NzR.y;
+		if (REFL) {
+			ReflFwdOut ro;
+			refl_forward_pixel<true>(rf.cam, rf.cubemap, rf.rgba, rf.fail_value, rf.L, st.Nxy.x, st.Nxy.y, st.NzR.x, px, py, st.NzR.y, c0, c1, c2, rf.no_key, ro);
+			if (rf.sort_keys) rf.sort_keys[p] = ro.key;
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) {
+				rf.out_final[ch * HW + p] = ro.final_c[ch];
+				rf.out_refl_color[ch * HW + p] = ro.refl_c[ch];
+			}
+			rf.out_nworld[p] = ro.nx;
+			rf.out_nworld[HW + p] = ro.ny;
+			rf.out_nworld[2 * HW + p] = ro.nz;
+		}
 		out_others[0 * HW + p] = st.DM.x;
 		out_others[1 * HW + p] = 1 - T;
 		out_others[2 * HW + p] = st.Nxy.x;
@@ -918,10 +964,6 @@ __device__ __forceinline__ void quat_vjp(float w, float x, float y, float z, con
 // Writes every output element (zeros for culled surfels).
 // ACC: the parameter gradients (mean3D, sh, opacity, scale, rotation, refl strength) are ADDED to the output tensors instead
 // of written: several views accumulate into one gradient buffer on the device (gsr_surfel_backward_accum).
-template <bool ACC> __device__ __forceinline__ void put(float* p, float v) {
-	if (ACC) { if (v != 0.f) *p += v; }     // (a view adds nothing to the Gaussians it did not touch: no read, no write)
-	else *p = v;
-}
 template <bool ACC>
 __global__ void __launch_bounds__(256)
 surfel_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means, const int* __restrict__ radii, const float* __restrict__ shs,
@@ -1127,15 +1169,21 @@ static SurfelCam make_scam(const float* view, const float* proj, const float* ca
 	return c;
 }
 
-extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+extern "C" int gsr_surfel_forward_refl(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width, int height,
                                   const float* means3D, const uint8_t* env_scope_mask, const float* shs, const float* colors_precomp,
                                   const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
                                   const float* rotations, const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
                                   const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_others,
-                                  float* out_refl_strength_map, int* radii, float* gaussian_weights, int debug, void* stream_) {
+                                  float* out_refl_strength_map, int* radii, float* gaussian_weights, const gsr_refl_forward* refl, int debug,
+                                  void* stream_) {
 	hipStream_t stream = (hipStream_t)stream_;
 	if (!alloc || P < 0 || width <= 0 || height <= 0 || !background || !out_color || !out_others || !out_refl_strength_map) {
 		set_error("gsr_surfel_forward: invalid argument");
+		return GSR_E_INVALID;
+	}
+	if (refl && (!refl->cam || !refl->cubemap || !refl->fail_value || refl->L == 0 || !refl->cubemap_rgba || ((uintptr_t)refl->cubemap_rgba & 15) != 0 ||
+	             !refl->out_final || !refl->out_refl_color || !refl->out_normal_world)) {
+		set_error("gsr_surfel_forward_refl: incomplete reflection descriptor (cam, cubemap, fail_value, L, 16-byte aligned cubemap_rgba and the three outputs are required)");
 		return GSR_E_INVALID;
 	}
 	const size_t HW = (size_t)width * height;
@@ -1143,6 +1191,10 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 		GSR_HIP_CHECK(hipMemsetAsync(out_color, 0, HW * 3 * 4, stream));
 		GSR_HIP_CHECK(hipMemsetAsync(out_others, 0, HW * 8 * 4, stream));
 		GSR_HIP_CHECK(hipMemsetAsync(out_refl_strength_map, 0, HW * 4, stream));
+		if (refl)    // an empty scene through the stand-alone pixel pass: the same arithmetic on zero planes
+			return gsr_deferred_reflection_forward_keys(out_others + 2 * HW, out_color, out_refl_strength_map, refl->cam, refl->cubemap, refl->fail_value, refl->L,
+			                                            width, height, refl->out_final, refl->out_refl_color, refl->out_normal_world, refl->cubemap_rgba,
+			                                            refl->sort_keys, stream_) < 0 ? GSR_E_HIP : 0;
 		return 0;
 	}
 	if (!means3D || !opacities || !refl_strengths || !viewmatrix || !projmatrix || !cam_pos || !radii || !gaussian_weights ||
@@ -1167,9 +1219,14 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 
 	if (prefiltered) GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));   // the flag is only written and read then
 	const SurfelCam cam = make_scam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
+	CubemapInterleave ci{nullptr, nullptr, 0u, 1u};
+	if (refl) {
+		if ((size_t)6 * refl->L * refl->L >= 0xFFFFFFFFull) { set_error("gsr_surfel_forward_refl: cubemap too large"); return GSR_E_INVALID; }
+		ci = CubemapInterleave{refl->cubemap, reinterpret_cast<float4*>(refl->cubemap_rgba), 6u * refl->L * refl->L, refl->L * refl->L};
+	}
 { StageTimer st_(GSR_STAGE_PREPROCESS, stream); 	surfel_preprocess_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
 	                                                              transMat_precomp, colors_precomp, refl_strengths, env_scope_mask, cam, radii, geom,
-	                                                              tiles_x, tiles_y, prefiltered, gaussian_weights); }
+	                                                              tiles_x, tiles_y, prefiltered, gaussian_weights, ci); }
 	GSR_LAUNCH_CHECK(debug, stream);
 
 	BinningState bin;
@@ -1178,11 +1235,34 @@ extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, i
 
 { StageTimer st_(GSR_STAGE_RENDER_FWD, stream);
 	const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
-	surfel_render_fwd_wave_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
-	                                                         option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
-	                                                         out_refl_strength_map, gaussian_weights, bin.blend_mask, bin.mask_stride); }
+	if (refl) {
+		const SurfelReflFwd rf{refl->cam, refl->cubemap, reinterpret_cast<const float4*>(refl->cubemap_rgba), refl->fail_value, (int)refl->L, 6u * refl->L * refl->L,
+		                       refl->out_final, refl->out_refl_color, refl->out_normal_world, refl->sort_keys};
+		surfel_render_fwd_wave_kernel<true><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+		                                                               option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
+		                                                               out_refl_strength_map, gaussian_weights, bin.blend_mask, bin.mask_stride, rf);
+	} else {
+		surfel_render_fwd_wave_kernel<false><<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, geom.rec, geom.bbox,
+		                                                                option_cull(), background, img.final_T, img.n_contrib, out_color, out_others,
+		                                                                out_refl_strength_map, gaussian_weights, bin.blend_mask, bin.mask_stride, SurfelReflFwd{});
+	} }
 	GSR_LAUNCH_CHECK(debug, stream);
+	if (refl && refl->sort_keys && refl->scratch) {
+		const int rc = refl_sort_keys_early(refl->L, width, height, refl->scratch, refl->scratch_floats, refl->sort_keys, refl->async_sort, stream);
+		if (rc < 0) return rc;
+	}
 	return R;
+}
+
+extern "C" int gsr_surfel_forward(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                                  const float* means3D, const uint8_t* env_scope_mask, const float* shs, const float* colors_precomp,
+                                  const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
+                                  const float* rotations, const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                                  const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_others,
+                                  float* out_refl_strength_map, int* radii, float* gaussian_weights, int debug, void* stream_) {
+	return gsr_surfel_forward_refl(alloc, alloc_user, P, D, M, background, width, height, means3D, env_scope_mask, shs, colors_precomp, refl_strengths, opacities,
+	                               scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+	                               out_others, out_refl_strength_map, radii, gaussian_weights, nullptr, debug, stream_);
 }
 
 extern "C" int gsr_surfel_backward_ex(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -1215,6 +1295,9 @@ extern "C" int gsr_surfel_backward_ex(int P, int D, int M, int R, const float* b
 
 	GSR_HIP_CHECK(hipMemsetAsync(geom.acc, 0, (size_t)P * S_ACC_F * sizeof(float), stream));
 	if (R > 0) {
+		// a key sort of the reflection backward on the library's side stream must have reached its last pass before this kernel takes
+		// every wave slot of the chip (side_gate_wait, gsr_cubemap.hip); nothing pending: no wait
+		{ const int rc = side_gate_wait(stream); if (rc < 0) return rc; }
 { StageTimer st_(GSR_STAGE_RENDER_BWD, stream);
 		const int nunits = (int)xcd_grid((uint32_t)ntiles * 4u);
 		surfel_render_bwd_rows_kernel<<<nunits, 64, 0, stream>>>(img.ranges, img.tile_order, bin.point_list, width, height, tiles_x, ntiles, background, geom.rec,

@@ -53,6 +53,8 @@ _VARIANT = Variant(
     saved=("colors_precomp", "normals", "refl_strengths", "means3D", "scales", "rotations", "cov3Ds_precomp", "sh", "opacities"),
     pack_backward=_pack_backward, grads_of=_grads_of,
     optional_grads=("sh", "colors_precomp", "scales", "rotations", "cov3Ds_precomp"),
+    sinkable={"means3D": "means3D", "sh": "shs", "opacities": "opacities", "scales": "scales", "rotations": "rotations",
+              "refl_strengths": "refl_strengths", "normals": "normals"},
     skippable={"colors_precomp": "colors", "cov3Ds_precomp": "cov3D"})
 
 GaussianRasterizationSettings, _RasterizeGaussians, rasterize_gaussians, GaussianRasterizer = build_api(_VARIANT)

@@ -5,6 +5,7 @@ positional arguments and return tuples, implemented over the C ABI of libgsr_hip
 Tensor plumbing follows RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible of
 submodules/diff-surfel-rasterization/rasterize_points.cu:39-151, 153-267, 269-288.
 """
+import ctypes
 import os
 import sys
 
@@ -20,8 +21,14 @@ SINKABLE = frozenset(("means3D", "shs", "opacities", "scales", "rotations", "ref
 
 def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations, scale_modifier,
                         transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    if _gsr.PYBIND is not None:      # GSR_BINDING=pybind: the compiled marshaling (csrc/gsr_torch_binding.cpp) instead of ctypes
+                        prefiltered, debug, *, refl=None):
+    """Same positional arguments and return tuple as the reference's `_C.rasterize_gaussians` (DSR rasterize_points.cu:39-151).
+    Keyword-only extension `refl` (round 4, the fused rasterize + reflect path, gsr_surfel_forward_refl): a dict with `cam` (the 33-float
+    camera block of gaussian_renderer._cam_block), `cubemap` [6,3,L,L], `fail_value` [3] and `keys` (bool: also write the sort keys of the
+    backward's footprint records).  The deferred-reflection pass then runs as the epilogue of the tile kernel and the return tuple grows
+    by (final[3,H,W], refl_color[3,H,W], normal_world[3,H,W], cubemap_rgba, sort_keys | None, scratch | None); `early_sort`: the forward
+    also sorts the keys on the library's side stream into `scratch`, which the reflection backward then takes (keys_sorted)."""
+    if _gsr.PYBIND is not None and refl is None:      # GSR_BINDING=pybind: the compiled marshaling (csrc/gsr_torch_binding.cpp) instead of ctypes
         return _gsr.PYBIND.surfel_rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_strengths, opacity, scales, rotations,
                                                       float(scale_modifier), transMat_precomp, viewmatrix, projmatrix, float(tan_fovx),
                                                       float(tan_fovy), int(image_height), int(image_width), sh, int(degree), campos,
@@ -51,17 +58,35 @@ def rasterize_gaussians(background, means3D, env_scope_mask, colors, refl_streng
             f32c(refl_strengths, "refl_strengths"), f32c(opacity, "opacity"), f32c(scales, "scales"), f32c(rotations, "rotations"),
             f32c(transMat_precomp, "transMat_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"),
             f32c(campos, "campos")]
-    bg, m3, shc, col, refl, opa, sca, rot, tmp, vm, pm, cp = keep
+    bg, m3, shc, col, rfl, opa, sca, rot, tmp, vm, pm, cp = keep
+    desc, extra = None, ()
+    if refl is not None:
+        cm, fv, cam = f32c(refl["cubemap"], "cubemap"), f32c(refl["fail_value"], "fail_value"), f32c(refl["cam"], "cam")
+        if cm.dim() != 4 or cm.shape[0] != 6 or cm.shape[1] != 3 or cm.shape[2] != cm.shape[3]:
+            raise RuntimeError("rasterize + reflect: the cubemap must be (6, 3, L, L)")
+        L = int(cm.shape[2])
+        final, refl_color, normal_world = (torch.empty((3, H, W), **fopts) for _ in range(3))
+        rgba = torch.empty(6 * L * L * 4, **fopts)
+        keys = torch.empty(H * W, dtype=torch.int32, device=dev) if refl.get("keys") else None
+        # early_sort: the forward also sorts the keys (on the side stream) into the scratch the reflection backward will use
+        scratch = None
+        if keys is not None and refl.get("early_sort"):
+            scratch = torch.empty(int(lib.gsr_deferred_reflection_scratch_floats(L, W, H, 1)), **fopts)
+        desc = _gsr.ReflForward(ptr(cam), ptr(cm), ptr(fv), L, ptr(rgba), ptr(final), ptr(refl_color), ptr(normal_world), ptr(keys), ptr(scratch),
+                                scratch.numel() if scratch is not None else 0, 1 if scratch is not None else 0)
+        keep += [cm, fv, cam]
+        extra = (final, refl_color, normal_world, rgba, keys, scratch)
     with torch.cuda.device(dev):
-        rendered = check(lib.gsr_surfel_forward(ws.cb, None, P, int(degree), M, ptr(bg), W, H, ptr(m3), ptr(mask), ptr(shc), ptr(col),
-                                                ptr(refl), ptr(opa), ptr(sca), float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm),
-                                                ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), ptr(out_color),
-                                                ptr(out_others), ptr(out_refl), ptr(radii), ptr(gaussian_weights), int(bool(debug)),
-                                                stream_ptr(dev)), "gsr_surfel_forward")
+        rendered = check(lib.gsr_surfel_forward_refl(ws.cb, None, P, int(degree), M, ptr(bg), W, H, ptr(m3), ptr(mask), ptr(shc), ptr(col),
+                                                     ptr(rfl), ptr(opa), ptr(sca), float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm),
+                                                     ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), ptr(out_color),
+                                                     ptr(out_others), ptr(out_refl), ptr(radii), ptr(gaussian_weights),
+                                                     ctypes.byref(desc) if desc is not None else None, int(bool(debug)), stream_ptr(dev)),
+                         "gsr_surfel_forward")
     if ws.error is not None:
         raise ws.error
     geomBuffer, binningBuffer, imgBuffer = ws.bufs
-    return rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer, out_refl, gaussian_weights
+    return (rendered, out_color, out_others, radii, geomBuffer, binningBuffer, imgBuffer, out_refl, gaussian_weights) + extra
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, refl_strengths, scales, rotations, scale_modifier, transMat_precomp,
@@ -91,8 +116,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
     if unused - {"colors", "transMat"} or ("colors" in unused and sh.numel() == 0) or ("transMat" in unused and scales.numel() == 0):
         raise ValueError("unused: 'colors' needs shs as the colour input, 'transMat' needs scales / rotations; got %r" % (sorted(unused),))
     if extra_normal_grad is not None:
-        if tuple(extra_normal_grad.shape) != (3,) + tuple(dL_dout_color.shape[1:]) or extra_normal_grad.device != means3D.device:
-            raise ValueError(f"extra_normal_grad: expected (3, H, W) = {(3,) + tuple(dL_dout_color.shape[1:])} on {means3D.device}, "
+        hw = tuple(dL_dout_color.shape[1:])
+        if tuple(extra_normal_grad.shape) != (3,) + hw or extra_normal_grad.device != means3D.device:
+            raise ValueError(f"extra_normal_grad: expected (3, H, W) = {(3,) + hw} on {means3D.device}, "
                              f"got {tuple(extra_normal_grad.shape)} on {extra_normal_grad.device}")
     if _gsr.PYBIND is not None and not grad_sink and extra_normal_grad is None:
         return _gsr.PYBIND.surfel_rasterize_gaussians_backward(
@@ -139,10 +165,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, refl_streng
                 f32c(transMat_precomp, "transMat_precomp"), f32c(viewmatrix, "viewmatrix"), f32c(projmatrix, "projmatrix"),
                 f32c(campos, "campos"), f32c(dL_dout_color, "dL_dout_color"), f32c(dL_dout_others, "dL_dout_others"),
                 f32c(dL_dout_refl_strength_map, "dL_dout_refl_strength_map"), radii.contiguous()]
-        bg, m3, shc, col, refl, sca, rot, tmp, vm, pm, cp, gcol, goth, grefl, rad = keep
+        bg, m3, shc, col, rfl, sca, rot, tmp, vm, pm, cp, gcol, goth, grefl, rad = keep
         gnx = f32c(extra_normal_grad, "extra_normal_grad") if extra_normal_grad is not None else None
         with torch.cuda.device(dev):
-            check(lib.gsr_surfel_backward_ex(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(refl), ptr(sca),
+            check(lib.gsr_surfel_backward_ex(P, int(degree), M, int(R), ptr(bg), W, H, ptr(m3), ptr(shc), ptr(col), ptr(rfl), ptr(sca),
                                           float(scale_modifier), ptr(rot), ptr(tmp), ptr(vm), ptr(pm), ptr(cp), float(tan_fovx),
                                           float(tan_fovy), ptr(rad), ptr(geomBuffer), ptr(binningBuffer), ptr(imageBuffer), ptr(gcol),
                                           ptr(goth), ptr(grefl), ptr(dL_dmeans2D), ptr(dL_dnormal), ptr(dL_dopacity), ptr(dL_dcolors),

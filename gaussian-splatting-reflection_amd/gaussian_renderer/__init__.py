@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _gsr  # noqa: E402
 from _gsr import check, lib, ptr, stream_ptr  # noqa: E402
 from _raster_api import GradSink  # noqa: E402
+import diff_surfel_rasterization as _dsr  # noqa: E402
 from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
 
 
@@ -119,7 +120,7 @@ class _DeferredReflection(torch.autograd.Function):
         if REFLECTION_BACKWARD_BINNED and REFLECTION_FORWARD_KEYS and any(ctx.needs_input_grad[:5]):
             keys = torch.empty(H * W, dtype=torch.int32, device=cm.device)
         with torch.cuda.device(nv.device):
-            check(lib.gsr_deferred_reflection_forward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(final),
+            check(lib.gsr_deferred_reflection_forward_keys(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H, ptr(final),
                                                          ptr(refl_color), ptr(normal_world), ptr(rgba), ptr(keys), stream_ptr(nv.device)),
                   "gsr_deferred_reflection_forward")
         ctx.save_for_backward(nv, bc, rs, cm, fv, cam, rgba)
@@ -155,10 +156,10 @@ class _DeferredReflection(torch.autograd.Function):
         if async_tail and not (sunk_cm and sunk_fail):
             raise ValueError("reflection grad sink: async_tail=True needs both 'cubemap' and 'fail' tensors")
         with torch.cuda.device(nv.device):
-            check(lib.gsr_deferred_reflection_backward_ex(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
+            check(lib.gsr_deferred_reflection_backward_keys(ptr(nv), ptr(bc), ptr(rs), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
                                                           ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base),
                                                           ptr(g_s), ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(accumulate),
-                                                          int(async_tail), ptr(rgba), ptr(ctx.sort_keys), stream_ptr(nv.device)),
+                                                          int(async_tail), ptr(rgba), ptr(ctx.sort_keys), 0, stream_ptr(nv.device)),
                   "gsr_deferred_reflection_backward")
         if async_tail:
             _gsr.side_hold(scratch, g_cm, g_fail, ctx.sort_keys)     # read / written on the side stream until side_join()
@@ -185,6 +186,141 @@ def deferred_reflection(normal_view, base_color, refl_strength_map, env_map, wor
     sink = GradSink(grad_sink, accumulate, async_tail) if grad_sink else None
     return _DeferredReflection.apply(normal_view, base_color, refl_strength_map, env_map.params['Cubemap_texture'],
                                      env_map.params['Cubemap_failv'], cam, sink)
+
+
+# ------------------------------------------------------------------------------------------- rasterizer + reflection in one pass
+# True (round 4): render() / render_fast() run the deferred reflection's forward INSIDE the rasterizer's forward tile kernel and both
+# backwards in one autograd node (rasterize_reflect below); False: rasterizer, then deferred_reflection() as two autograd nodes.  Same
+# outputs (tests/test_gpu_fused.py).
+FUSED_REFLECTION = True
+
+
+class _RasterizeReflect(torch.autograd.Function):
+    """Surfel rasterizer + deferred reflection as ONE autograd node.  Forward: gsr_surfel_forward_refl — the reflection's per-pixel code
+    runs as the epilogue of the forward tile kernel (csrc/gsr_surfel.hip, csrc/gsr_refl.hpp) and the texel-interleaved cubemap copy is made
+    by the per-Gaussian kernel: no pixel kernel, no interleave dispatch, no re-read of the seven planes the two passes exchanged.
+    Backward: the reflection's pixel kernel and then the rasterizer's backward, back to back in one node (no autograd glue between them;
+    the pixel gradients reach the tile backward as pointers).  The reflection backward is NOT folded into the tile backward: its
+    texel-gradient tail (sort by texel, run combine) needs every pixel's record early so that it hides beside that kernel — as a prologue
+    of the tile backward the records are complete only when it ends and the tail is exposed (built and measured in round 4).
+    apply(*rasterizer tensors in diff_surfel_rasterization's order, cubemap, fail_value, cam_block, settings, raster_sink, refl_sink)
+    -> (final, refl_color, normal_world, base_color, radii, allmap, refl_strength_map, gaussian_weights)."""
+    V = _dsr._VARIANT
+    probe = None        # tests only: a dict that receives clones of the pixel gradients the reflection backward hands the rasterizer backward
+
+    @staticmethod
+    def forward(ctx, *args):
+        v = _RasterizeReflect.V
+        n = len(v.tensors)
+        t = dict(zip(v.tensors, args[:n]))
+        cubemap, fail_value, cam, settings, raster_sink, refl_sink = args[n:]
+        cm, fv = cubemap.float().contiguous(), fail_value.float().contiguous()
+        if cm.dim() != 4 or cm.shape[1] != 3:
+            raise RuntimeError("rasterize_reflect: the cubemap must be (6, 3, L, L)")
+        want_keys = REFLECTION_BACKWARD_BINNED and REFLECTION_FORWARD_KEYS and any(ctx.needs_input_grad[:n + 2])
+        # With an asynchronous tail the keys are sorted HERE, on the side stream behind the forward's tile kernel: the sort then runs beside
+        # whatever follows the forward (the loss, the start of the backward) instead of racing the tile backward for CUs
+        early = want_keys and refl_sink is not None and refl_sink.async_tail and bool(refl_sink.tensors)
+        ret = _dsr._C.rasterize_gaussians(*v.pack_forward(t, settings), refl=dict(cam=cam, cubemap=cm, fail_value=fv, keys=want_keys, early_sort=early))
+        (num_rendered, color, others, radii, geom, binning, img, refl_map, weights, final, refl_color, normal_world, rgba, keys, scratch) = ret
+        if scratch is not None:
+            _gsr.side_hold(scratch, keys)       # the side stream reads / writes them from now on (until side_join)
+        ctx.raster_settings, ctx.num_rendered, ctx.n_tensors = settings, num_rendered, n
+        ctx.raster_sink, ctx.refl_sink, ctx.sort_keys, ctx.scratch = raster_sink, refl_sink, keys, scratch
+        ctx.save_for_backward(*[t[k] for k in v.saved], radii, geom, binning, img, color, others, refl_map, cm, fv, cam, rgba)
+        ctx.mark_non_differentiable(radii, weights)
+        ctx.set_materialize_grads(False)
+        return final, refl_color, normal_world, color, radii, others, refl_map, weights
+
+    @staticmethod
+    def backward(ctx, g_final, g_refl_color, g_normal_world, g_color, _g_radii, g_others, g_refl_map, _g_weights):
+        v = _RasterizeReflect.V
+        kept = ctx.saved_tensors
+        ns = len(v.saved)
+        saved = dict(zip(v.saved, kept[:ns]))
+        radii, geom, binning, img, color, others, refl_map, cm, fv, cam, rgba = kept[ns:]
+        settings = ctx.raster_settings
+        cont = lambda g: None if g is None else g.float().contiguous()
+        H, W = color.shape[1], color.shape[2]
+        dev = color.device
+        # ---- 1. reflection backward (pixel kernel on this stream, texel-gradient tail beside what follows)
+        g_final = torch.zeros_like(color) if g_final is None else cont(g_final)
+        g_refl_color, g_normal_world = cont(g_refl_color), cont(g_normal_world)
+        rs = ctx.refl_sink.tensors if ctx.refl_sink is not None else {}
+        acc_refl = ctx.refl_sink is not None and ctx.refl_sink.accumulate
+        async_tail = ctx.refl_sink is not None and ctx.refl_sink.async_tail
+        g_cm, g_fail = rs.get("cubemap"), rs.get("fail")
+        sunk_cm, sunk_fail = g_cm is not None, g_fail is not None
+        if (acc_refl or async_tail) and not (sunk_cm and sunk_fail):
+            raise ValueError("reflection grad sink: accumulate / async_tail need both 'cubemap' and 'fail' tensors")
+        for tt, like, name in ((g_cm, cm, "cubemap"), (g_fail, fv, "fail")):
+            if tt is not None and (tuple(tt.shape) != tuple(like.shape) or tt.dtype != torch.float32 or not tt.is_contiguous() or tt.device != like.device):
+                raise ValueError(f"reflection grad sink '{name}': expected contiguous float32 {tuple(like.shape)} on {like.device}")
+        g_cm = torch.empty_like(cm) if g_cm is None else g_cm
+        g_fail = torch.empty_like(fv) if g_fail is None else g_fail
+        keys_sorted = ctx.scratch is not None
+        if keys_sorted:
+            scratch, n_scratch = ctx.scratch, int(ctx.scratch.numel())
+        else:
+            n_scratch = int(lib.gsr_deferred_reflection_scratch_floats(int(cm.shape[2]), W, H, 1 if REFLECTION_BACKWARD_BINNED else 0))
+            scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+        g_nv, g_base, g_s = torch.empty((3, H, W), dtype=torch.float32, device=dev), torch.empty_like(color), torch.empty_like(refl_map)
+        nv = others[2:5]                          # (contiguous: planes 2..4 of the [8,H,W] output)
+        with torch.cuda.device(dev):
+            check(lib.gsr_deferred_reflection_backward_keys(ptr(nv), ptr(color), ptr(refl_map), ptr(cam), ptr(cm), ptr(fv), cm.shape[2], W, H,
+                                                            ptr(g_final), ptr(g_refl_color), ptr(g_normal_world), ptr(g_nv), ptr(g_base), ptr(g_s),
+                                                            ptr(g_cm), ptr(g_fail), ptr(scratch), n_scratch, int(acc_refl), int(async_tail),
+                                                            ptr(rgba), ptr(ctx.sort_keys), int(keys_sorted), stream_ptr(dev)),
+                  "gsr_deferred_reflection_backward")
+        if async_tail:
+            _gsr.side_hold(scratch, g_cm, g_fail, ctx.sort_keys)     # read / written on the side stream until side_join()
+        # ---- 2. rasterizer backward: what reached its colour / reflection-strength outputs through the final image, plus the direct gradients
+        # of those outputs (rare: nothing in the reference's losses reads them); the normal gradient travels as the tap's pointer
+        g_color, g_refl_map, g_others = cont(g_color), cont(g_refl_map), cont(g_others)
+        if g_color is not None:
+            g_base.add_(g_color)
+        if g_refl_map is not None:
+            g_s.add_(g_refl_map)
+        if g_others is None:
+            g_others = torch.zeros_like(others)
+        if _RasterizeReflect.probe is not None:
+            _RasterizeReflect.probe.update(g_normal_view=g_nv.clone(), g_base=g_base.clone(), g_strength=g_s.clone())
+        c_args = v.pack_backward(saved, settings, [g_base, None, g_others, g_s, None], ctx.num_rendered, (geom, binning, img), radii)
+        kw = {"extra_normal_grad": g_nv}
+        sink = ctx.raster_sink.tensors if (ctx.raster_sink is not None and ctx.raster_sink.tensors) else {}
+        if sink:
+            kw.update(grad_sink=sink, accumulate=ctx.raster_sink.accumulate)
+        unused = tuple(key for name, key in v.skippable.items() if saved.get(name) is None or saved[name].numel() == 0)
+        if unused:
+            kw["unused"] = unused
+        g = v.grads_of(_dsr._C.rasterize_gaussians_backward(*c_args, **kw))
+        out = []
+        for name in v.tensors:
+            grad = g.get(name)
+            if name in v.sinkable and v.sinkable[name] in sink:
+                grad = None            # already written (or added) into the caller's sink tensor by the backward kernel
+            elif name in v.optional_grads and (saved.get(name) is None or saved[name].numel() == 0):
+                grad = None
+            out.append(grad)
+        return tuple(out) + ((None if sunk_cm else g_cm), (None if sunk_fail else g_fail), None, None, None, None)
+
+
+def rasterize_reflect(rasterizer, env_map, world_view_transform, HWK, R, T, means3D, means2D, opacities, shs=None, colors_precomp=None,
+                      refl_strengths=None, scales=None, rotations=None, cov3D_precomp=None, env_scope_mask=None, refl_grad_sink=None,
+                      accumulate=False, async_tail=False):
+    """Extension: `rasterizer(...)` followed by `deferred_reflection(allmap[2:5], base, refl_map, env_map, ...)` as ONE pass over the
+    pixels (see _RasterizeReflect).  `rasterizer`: a diff_surfel_rasterization.GaussianRasterizer (its settings and its gradient sink —
+    set_grad_sink — apply); the keyword arguments are those of its forward(); refl_grad_sink / accumulate / async_tail those of
+    deferred_reflection().  Returns (final_image, refl_color, rend_normal_world, base_color, radii, allmap, refl_strength_map,
+    gaussian_weights)."""
+    if async_tail and not refl_grad_sink:
+        raise ValueError("rasterize_reflect: async_tail=True needs a refl_grad_sink (autograd would read the gradient at once)")
+    t = rasterizer._collect(means3D, means2D, opacities, shs=shs, colors_precomp=colors_precomp, refl_strengths=refl_strengths, scales=scales,
+                            rotations=rotations, cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask)
+    cam = _cam_block(world_view_transform, HWK, R, T)
+    rsink = GradSink(refl_grad_sink, accumulate, async_tail) if refl_grad_sink else None
+    return _RasterizeReflect.apply(*[t[name] for name in _dsr._VARIANT.tensors], env_map.params['Cubemap_texture'], env_map.params['Cubemap_failv'], cam,
+                                   rasterizer.raster_settings, rasterizer._grad_sink, rsink)
 
 
 class _ShadingNormal(torch.autograd.Function):
@@ -311,12 +447,21 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     else:
         scales, rotations = pc.get_scaling, pc.get_rotation
     shs = pc.get_features if override_color is None else None       # SH evaluation always happens in the rasterizer
-    base_color, radii, allmap, refl_strength_map, gaussian_weights, normal_view = rasterizer(
-        means3D=xyz, means2D=means2D, shs=shs, colors_precomp=override_color, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask)
+    v = viewpoint_camera
+    fused = FUSED_REFLECTION and not initial_stage
+    if fused:
+        rasterizer.set_output_taps(())
+        (final_image, refl_color, rend_normal, base_color, radii, allmap, refl_strength_map, gaussian_weights) = rasterize_reflect(
+            rasterizer, pc.get_envmap, v.world_view_transform, v.HWK, v.R, v.T, means3D=xyz, means2D=means2D, shs=shs,
+            colors_precomp=override_color, refl_strengths=pc.get_refl, opacities=pc.get_opacity, scales=scales, rotations=rotations,
+            cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask, refl_grad_sink=refl_sink, accumulate=accumulate,
+            async_tail=async_tail and bool(refl_sink))
+    else:
+        base_color, radii, allmap, refl_strength_map, gaussian_weights, normal_view = rasterizer(
+            means3D=xyz, means2D=means2D, shs=shs, colors_precomp=override_color, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, env_scope_mask=env_scope_mask)
 
     surf_depth, surf_normal = surface_pass(allmap, viewpoint_camera, pipe.depth_ratio)
-    v = viewpoint_camera
     out = {"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "rend_alpha": allmap[1:2],
            "rend_dist": allmap[6:7], "surf_depth": surf_depth, "surf_normal": surf_normal, "gaussian_weights": gaussian_weights,
            "env_scope_mask": allmap[7:8]}
@@ -324,9 +469,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         out["rend_normal"] = shading_normal(normal_view, v.world_view_transform, v.HWK, v.R, v.T)
         out["render"] = base_color
         return out
-    final_image, refl_color, rend_normal = deferred_reflection(normal_view, base_color, refl_strength_map, pc.get_envmap,
-                                                               v.world_view_transform, v.HWK, v.R, v.T, grad_sink=refl_sink,
-                                                               accumulate=accumulate, async_tail=async_tail and bool(refl_sink))
+    if not fused:
+        final_image, refl_color, rend_normal = deferred_reflection(normal_view, base_color, refl_strength_map, pc.get_envmap,
+                                                                   v.world_view_transform, v.HWK, v.R, v.T, grad_sink=refl_sink,
+                                                                   accumulate=accumulate, async_tail=async_tail and bool(refl_sink))
     out.update({"rend_normal": rend_normal, "render": final_image, "refl_strength_map": refl_strength_map, "refl_color_map": refl_color,
                 "base_color_map": base_color})
     return out
@@ -338,10 +484,17 @@ def render_fast(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, init
     xyz = pc.get_xyz
     means2D = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
+    v = viewpoint_camera
+    if FUSED_REFLECTION and not initial_stage:
+        final_image, refl_color, rend_normal, base_color, _, allmap, refl_strength_map, _ = rasterize_reflect(
+            rasterizer, pc.get_envmap, v.world_view_transform, v.HWK, v.R, v.T, means3D=xyz, means2D=means2D, shs=pc.get_features,
+            refl_strengths=pc.get_refl, opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation,
+            env_scope_mask=torch.ones_like(xyz).bool())
+        return {"render": final_image, "rend_alpha": allmap[1:2], "rend_normal": rend_normal, "refl_strength_map": refl_strength_map,
+                "refl_color_map": refl_color, "base_color_map": base_color}
     base_color, _, allmap, refl_strength_map, _ = rasterizer(
         means3D=xyz, means2D=means2D, shs=pc.get_features, colors_precomp=None, refl_strengths=pc.get_refl, opacities=pc.get_opacity,
         scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None, env_scope_mask=torch.ones_like(xyz).bool())
-    v = viewpoint_camera
     if initial_stage:
         return {"render": base_color, "rend_alpha": allmap[1:2], "refl_strength_map": refl_strength_map,
                 "rend_normal": shading_normal(allmap[2:5], v.world_view_transform, v.HWK, v.R, v.T)}

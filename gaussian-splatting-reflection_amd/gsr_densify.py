@@ -50,11 +50,43 @@ def _gather(src_flat, dst_flat, row_map, old, new, names):
               "gsr_gather_rows")
 
 
-def densify_and_prune(state, stats, max_grad, min_opacity, mean, extent, max_screen_size, percent_dense=0.01, N=2, noise=None):
+def _whole_moments(state, group):
+    """Both Adam moment buffers over the WHOLE flat layout.  Unsharded state: the optimizer's own tensors.  Sharded state
+    (GaussianTrainState(shard=(rank, N)): the optimizer holds total / N floats, the chunk this rank steps): the chunks of all ranks,
+    all-gathered in rank order = buffer order — the row map below addresses rows by their offsets in the whole buffer, and a chunk
+    border falls anywhere, also inside a parameter group."""
+    import torch.distributed as dist
+    opt, total = state.optimizer, state.params.total
+    a, b = opt.owned
+    if (a, b) == (0, total):
+        return opt.exp_avg, opt.exp_avg_sq
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) * (b - a) != total:
+        raise RuntimeError("densify_and_prune: the train state is sharded (%r) but there is no process group of that size to gather the Adam "
+                           "moments from" % (state.shard,))
+    out = []
+    for part in (opt.exp_avg, opt.exp_avg_sq):
+        if dist.get_backend(group) == "nccl":
+            full = torch.empty(total, dtype=part.dtype, device=part.device)
+            dist.all_gather_into_tensor(full, part.contiguous(), group=group)
+        else:                               # gloo (the CPU-rank rehearsal of the tests): staged through host memory
+            host = torch.empty(total, dtype=part.dtype)
+            dist.all_gather_into_tensor(host, part.detach().cpu().contiguous(), group=group)
+            full = host.to(part.device)
+        out.append(full)
+    return out[0], out[1]
+
+
+def densify_and_prune(state, stats, max_grad, min_opacity, mean, extent, max_screen_size, percent_dense=0.01, N=2, noise=None, group=None):
     """GaussianModel.densify_and_prune (scene/gaussian_model.py:548-576) on a GaussianTrainState.  Returns
     (new_state, new_stats, info).  `noise`: optional standard-normal tensor (N*k, scale_dims) for the k split parents (the
     reference draws it with torch.normal); drawn with torch.randn when None.  min_opacity is unused, as in the reference
-    (its opacity prune is commented out, :561-562)."""
+    (its opacity prune is commented out, :561-562).
+    Sharded state (view-parallel training with gsr_dist.ShardedStep): every rank holds all parameters and, after
+    gsr_dist.reduce_densification_stats, the same statistics, so every rank takes the same decisions — given the same `noise`, which the
+    caller must then supply (e.g. drawn on rank 0 and broadcast) — and rebuilds the same parameter buffer; the Adam moments, of which a
+    rank holds only its chunk, are all-gathered over `group`, permuted as a whole and re-cut into the new layout's chunks."""
+    if state.shard is not None and state.shard[1] > 1 and noise is None:
+        raise ValueError("densify_and_prune on a sharded state needs `noise` (identical on every rank): ranks drawing their own would split differently")
     old = state.params
     dev = old.flat.device
     names = [k for k in PER_GAUSSIAN if k in old.names]
@@ -111,12 +143,17 @@ def densify_and_prune(state, stats, max_grad, min_opacity, mean, extent, max_scr
     map_moment = torch.where(is_new[keep], torch.full_like(map_param, -1), map_param).contiguous()
     # -- one gather per flat buffer into a new store of P1 rows
     shapes = {kk: ((P1,) + old.shapes[kk][1:] if kk in names else old.shapes[kk]) for kk in old.names}
-    new = FlatParams(None, dev, shapes=shapes)
-    new_state = GaussianTrainState(None, dev, spatial_lr_scale=state.spatial_lr_scale, lrs=state.lrs, _params=new)
+    world = 1 if state.shard is None else state.shard[1]
+    new = FlatParams(None, dev, shapes=shapes, shards=world)             # (padded to `world` equal 16-byte-aligned chunks, as the old store was)
+    new_state = GaussianTrainState(None, dev, spatial_lr_scale=state.spatial_lr_scale, lrs=state.lrs, _params=new, shard=state.shard)
     opt_old, opt_new = state.optimizer, new_state.optimizer
+    old_avg, old_sq = _whole_moments(state, group)
+    sharded = opt_new.owned != (0, new.total)
+    new_avg = torch.zeros(new.total, dtype=torch.float32, device=dev) if sharded else opt_new.exp_avg
+    new_sq = torch.zeros(new.total, dtype=torch.float32, device=dev) if sharded else opt_new.exp_avg_sq
     _gather(old.flat, new.flat, map_param, old, new, names)
-    _gather(opt_old.exp_avg, opt_new.exp_avg, map_moment, old, new, names)
-    _gather(opt_old.exp_avg_sq, opt_new.exp_avg_sq, map_moment, old, new, names)
+    _gather(old_avg, new_avg, map_moment, old, new, names)
+    _gather(old_sq, new_sq, map_moment, old, new, names)
     with torch.no_grad():
         kept_child = is_child[keep]
         if bool(kept_child.any()):
@@ -128,8 +165,12 @@ def densify_and_prune(state, stats, max_grad, min_opacity, mean, extent, max_scr
                 a, b = old.slices[kk]
                 c, d = new.slices[kk]
                 new.flat[c:d].copy_(old.flat[a:b])
-                opt_new.exp_avg[c:d].copy_(opt_old.exp_avg[a:b])
-                opt_new.exp_avg_sq[c:d].copy_(opt_old.exp_avg_sq[a:b])
+                new_avg[c:d].copy_(old_avg[a:b])
+                new_sq[c:d].copy_(old_sq[a:b])
+        if sharded:                                                                     # this rank's chunk of the new layout
+            a2, b2 = opt_new.owned
+            opt_new.exp_avg.copy_(new_avg[a2:b2])
+            opt_new.exp_avg_sq.copy_(new_sq[a2:b2])
     opt_new.step_count = opt_old.step_count
     for kk in opt_old.groups:
         opt_new.groups[kk] = opt_old.groups[kk]

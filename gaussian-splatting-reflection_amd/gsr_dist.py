@@ -76,10 +76,12 @@ class FlatGrads:
         self._join()
         self.flat.zero_()
 
-    def sink(self, names=("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths")):
-        """Views of the flat buffer keyed by the rasterizer's gradient names, for GaussianRasterizer.set_grad_sink:
-        the backward kernels then write straight into the all-reduce payload (no zero-fill, no accumulate pass).
-        Valid for ONE backward per step and rank; with several views per step keep plain autograd accumulation."""
+    def sink(self, names=("means3D", "shs", "opacities", "scales", "rotations", "refl_strengths", "normals")):
+        """Views of the flat buffer keyed by the rasterizer's gradient names (those this buffer holds; `normals` is a parameter of
+        variant G only), for GaussianRasterizer.set_grad_sink: the backward kernels then write straight into the all-reduce payload
+        (no zero-fill, no accumulate pass).  Several views per step and rank: the first backward of the step with
+        set_grad_sink(sink, accumulate=False) overwrites the buffer, every further one with accumulate=True adds to it on the device
+        (kernel `+=`; bench.py's step_into, tests/test_gpu_api_paths.py::test_grad_sink_accumulates_views_on_the_device)."""
         return {k: self.view(k) for k in names if k in self.slices}
 
     def zero_except_(self, names):
@@ -135,8 +137,23 @@ class ShardedStep:
         n = total // self.world
         self.range = (self.rank * n, (self.rank + 1) * n)
         self.in_place = on and dist.get_backend(group) == "nccl"     # RCCL reduces / gathers in place when the shard is the rank's chunk of the buffer
+        self._gather = None        # the parameter all-gather of the last step(async_gather=True), still in flight
 
-    def step(self):
+    def wait(self):
+        """Makes the CURRENT stream wait for the parameter all-gather a step(async_gather=True) left in flight (no host block with RCCL).
+        Call it before the first kernel that reads the parameters — the next forward; step() calls it itself."""
+        if self._gather is not None:
+            work, keep = self._gather
+            self._gather = None
+            work.wait()
+            del keep
+
+    def step(self, async_gather=False):
+        """async_gather=True: the all-gather of the updated parameters is only STARTED (on the collective's own stream, behind the optimizer
+        kernel) and the call returns; whatever the caller enqueues next that does not read the parameters — the upload of the next
+        ground-truth image, the densification statistics of this step's views, host work — runs beside it, and wait() orders the next
+        forward behind it.  (The next forward itself cannot start earlier: its first kernel reads every parameter tensor.)"""
+        self.wait()
         st = self.state
         g, p = st.grads.flat, st.params.flat
         a, b = self.range
@@ -151,10 +168,11 @@ class ShardedStep:
         st.optimizer.step()                         # steps [a, b) only: its `owned` range
         if self.world > 1:
             with torch.no_grad():
-                if self.in_place:
-                    dist.all_gather_into_tensor(p, p[a:b], group=self.group)
+                src = p[a:b] if self.in_place else p[a:b].clone()
+                if async_gather:
+                    self._gather = (dist.all_gather_into_tensor(p, src, group=self.group, async_op=True), src)
                 else:
-                    dist.all_gather_into_tensor(p, p[a:b].clone(), group=self.group)
+                    dist.all_gather_into_tensor(p, src, group=self.group)
 
 
 def reduce_densification_stats(grad_norm_sum, visible_count, max_radii, group=None):

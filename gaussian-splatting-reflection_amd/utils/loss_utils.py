@@ -48,6 +48,10 @@ class _SsimL1(torch.autograd.Function):
                                           ptr(maps[0]) if need_grad else None, ptr(maps[1]) if need_grad else None,
                                           ptr(maps[2]) if need_grad else None, stream_ptr(dev)), "gsr_ssim_l1_forward")
         ctx.save_for_backward(x, y, maps)
+        # kept beside the saved tensors: l1_loss() and ssim() share this node (see _sums), and a caller who runs two backward passes —
+        # l1.backward(retain_graph=True) for the render graph, then ssim.backward(), two graphs in the reference — reaches it twice, the
+        # second time after autograd has released the saved tensors (x, y are inputs and maps an intermediate: no reference cycle)
+        ctx.kept = (x, y, maps)
         ctx.in_shape = img1.shape
         ctx.want_map = want_map
         if want_map:
@@ -57,7 +61,13 @@ class _SsimL1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sums, _):
-        x, y, maps = ctx.saved_tensors
+        global _last_sums
+        if _last_sums is not None and _last_sums[4].grad_fn is not None and getattr(_last_sums[4].grad_fn, "kept", None) is ctx.kept:
+            _last_sums = None          # consumed: a later l1_loss / ssim call on the same tensors starts a fresh forward (and a fresh graph)
+        try:
+            x, y, maps = ctx.saved_tensors      # (first pass: with autograd's check that nothing was modified in place since the forward)
+        except RuntimeError:
+            x, y, maps = ctx.kept               # a second pass through the shared node
         C, H, W = x.shape
         grad = torch.empty_like(x)
         w = f32c(g_sums, "grad_sums")
@@ -75,7 +85,10 @@ def _sums(img1, img2):
     tensors (train.py:167-173); both are read off ONE pair of sums, so the second call returns the first call's result (same tensor
     objects, unchanged since — version counters —, same grad mode) instead of running the fused forward, and later the fused backward,
     a second time.  The images are held weakly; the two-float result (and through its graph node the forward's saved planes, ~100 MB at
-    1080p) is held until the next call replaces it: the caller's `sums[0] / n` keeps the node alive, not the Python object."""
+    1080p, and the render graph behind the image) is held until a backward pass consumes it, the next call replaces it or
+    clear_cache() is called: the caller's `sums[0] / n` keeps the node alive, not the Python object.
+    What the key cannot see: an image buffer refilled through its raw pointer (this library's own C-ABI writes, `.data` assignments) keeps
+    object and version — call clear_cache() (or use photometric_loss, one explicit call) when reusing buffers that way."""
     global _last_sums
     if _last_sums is not None:
         r1, v1, r2, v2, s, mode = _last_sums
@@ -84,6 +97,12 @@ def _sums(img1, img2):
     s = _SsimL1.apply(img1, img2, C1, C2, False)[0]
     _last_sums = (weakref.ref(img1), img1._version, weakref.ref(img2), img2._version, s, torch.is_grad_enabled())
     return s
+
+
+def clear_cache():
+    """Forget the result shared between l1_loss() and ssim() (see _sums)."""
+    global _last_sums
+    _last_sums = None
 
 
 def l1_loss(network_output, gt):

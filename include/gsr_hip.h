@@ -49,6 +49,13 @@ extern "C" {
 typedef void* (*gsr_alloc_fn)(void* user, int which, size_t bytes);
 
 const char* gsr_last_error(void);
+/* ABI version of the library = GSR_ABI_VERSION of the header it was built from.  A binding checks gsr_version() == GSR_ABI_VERSION at load
+ * (gaussian-splatting-reflection_amd/_gsr.py does) so that a caller compiled against another header fails loudly instead of passing shifted
+ * arguments.  Rule: an exported entry point NEVER changes its signature; extensions get new symbols (…_accum, …_ex, …_keys, …_refl).
+ *   100  rounds 1-3.  Round 3 broke the rule once: gsr_deferred_reflection_forward_ex / _backward_ex gained a sort_keys argument in place.
+ *   101  round 4: those two are back to their round-2 signatures (no sort_keys) and the forms with keys are the new symbols
+ *        gsr_deferred_reflection_forward_keys / _backward_keys; new: gsr_gauss_backward_accum, gsr_surfel_forward_refl. */
+#define GSR_ABI_VERSION 101
 int gsr_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -117,6 +124,44 @@ int gsr_surfel_backward_ex(int P, int D, int M, int R, const float* background, 
                         float* dL_dsh, float* dL_dscale, float* dL_drot, int accumulate,
                         const float* dL_dnormal_extra, int debug, void* stream);
 
+/* Extension (round 4): the forward of rasterizer + deferred reflection in ONE pass over the pixels.  The reference runs the rasterizer,
+ * then ~12 torch ops per pixel (gaussian_renderer/__init__.py:22-35,143-199); gsr_deferred_reflection_forward below fuses those ops into
+ * one kernel; here that kernel's per-pixel code runs INSIDE the rasterizer's forward tile kernel, as its epilogue (a wave that has
+ * finished its 8x8 pixel block has normal, base colour and reflection strength in registers), and the texel-interleaved cubemap copy is
+ * made by the per-Gaussian kernel: no pixel kernel, no interleave dispatch, no re-read of seven planes.  All outputs of
+ * gsr_surfel_forward are still written.  The backward stays two calls (gsr_deferred_reflection_backward_keys, then
+ * gsr_surfel_backward_ex): its texel-gradient tail needs every pixel's record EARLY, so that it can hide beside the tile backward — run
+ * as a prologue of that kernel (built and measured, round 4) the records are complete only when the kernel ends and the tail is exposed.
+ *   refl == NULL: gsr_surfel_forward exactly.
+ * Forward descriptor: cam, cubemap [6,3,L,L], fail_value [3], L as gsr_deferred_reflection_forward; cubemap_rgba: 6*L*L*4 floats, 16-byte
+ * aligned, FILLED by the call (texel-interleaved copy, made by the per-Gaussian kernel) and to be handed to the backward; out_final,
+ * out_refl_color, out_normal_world [3,H,W]; sort_keys: NULL or width*height uint32 (see gsr_deferred_reflection_forward_keys).
+ * scratch (optional, with sort_keys): the buffer gsr_deferred_reflection_backward_keys will get.  The forward then also sorts the
+ * (key, pixel) pairs into it — with async_sort on the side stream, where the sort runs beside whatever follows the forward on `stream`
+ * (the loss; the start of the backward) while CUs are still free: 1024-thread sort workgroups cannot start on a chip the tile backward
+ * has filled.  Hand the SAME scratch, untouched, to the backward with keys_sorted = 1; it must stay alive until gsr_side_join. */
+typedef struct {
+	const float* cam;
+	const float* cubemap;
+	const float* fail_value;
+	uint32_t L;
+	float* cubemap_rgba;
+	float* out_final;
+	float* out_refl_color;
+	float* out_normal_world;
+	uint32_t* sort_keys;
+	float* scratch;          /* NULL, or (with sort_keys) the scratch of the backward: the call also SORTS the keys into it */
+	size_t scratch_floats;   /* gsr_deferred_reflection_scratch_floats(L, W, H, 1) */
+	int async_sort;          /* != 0: that sort runs on the library's side stream, forked behind the tile kernel */
+} gsr_refl_forward;
+int gsr_surfel_forward_refl(gsr_alloc_fn alloc, void* alloc_user, int P, int D, int M, const float* background, int width,
+                       int height, const float* means3D, const uint8_t* env_scope_mask, const float* shs,
+                       const float* colors_precomp, const float* refl_strengths, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                       float tan_fovy, int prefiltered, float* out_color, float* out_others,
+                       float* out_refl_strength_map, int* radii, float* gaussian_weights, const gsr_refl_forward* refl,
+                       int debug, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Variant G — 3D Gaussians with EWA projection, anti-aliasing and inverse depth.  Replaces
  * CudaRasterizer::Rasterizer::forward (DGR cuda_rasterizer/rasterizer.h:24-57, rasterizer_impl.cu:198-349).
@@ -146,6 +191,21 @@ int gsr_gauss_backward(int P, int D, int M, int R, const float* background, int 
                        float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth,
                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                        int antialiasing, int debug, void* stream);
+/* Extension (round 4; the counterpart of gsr_surfel_backward_accum): accumulate != 0 ADDS the seven PARAMETER gradients dL_dopacity,
+ * dL_dnormals, dL_drefl_strengths, dL_dmean3D, dL_dsh, dL_dscale, dL_drot to the given tensors (stream-ordered read-add-write in the
+ * per-Gaussian kernel, no atomics) instead of writing them: several views of a batch accumulate into one gradient buffer on the device.
+ * The per-view outputs dL_dmean2D, dL_dmean2D_pixels, dL_dconic, dL_dcolor, dL_dinvdepth, dL_dcov3D are overwritten in both modes. */
+int gsr_gauss_backward_accum(int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* normals,
+                       const float* refl_strengths, const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                       void* geom_buffer, void* binning_buffer, void* image_buffer, const float* dL_dpix,
+                       const float* dL_dnormal_map, const float* dL_drefl_strength_map, const float* dL_invdepths,
+                       float* dL_dmean2D, float* dL_dmean2D_pixels, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolor, float* dL_dnormals, float* dL_drefl_strengths, float* dL_dinvdepth,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                       int antialiasing, int accumulate, int debug, void* stream);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (DSR rasterizer.h:19-23, rasterizer_impl.cu:141-153). */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
@@ -216,24 +276,36 @@ int gsr_deferred_reflection_backward_accum(const float* normal_view, const float
  * g_strength are complete in `stream` order as always.  g_cubemap, g_fail and scratch must stay untouched and alive until
  * gsr_side_join(s) has been called: it makes stream s wait (device-side, no host block) for all side work enqueued so far
  * on the current device.  Successive tails are ordered among themselves (accumulate over a batch of views works).
- * sort_keys (NULL, or the width*height keys gsr_deferred_reflection_forward_ex wrote for the SAME inputs): the sort of the
- * footprint records then depends on nothing this call computes; with async_tail it forks before the pixel kernel and runs
- * beside it, and only the run combine waits for the records.  The keys must stay alive and untouched like scratch. */
+ * cubemap_rgba: NULL, or the texel-interleaved copy gsr_deferred_reflection_forward_ex made of the SAME cubemap. */
 int gsr_deferred_reflection_backward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
                                         const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
                                         int width, int height, const float* g_final, const float* g_refl_color,
                                         const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
                                         float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
+                                        int accumulate, int async_tail, const float* cubemap_rgba, void* stream);
+/* ... and with sort_keys (NULL, or the width*height keys gsr_deferred_reflection_forward_keys / gsr_surfel_forward_refl wrote for the SAME
+ * inputs): the sort of the footprint records then depends on nothing this call computes; with async_tail it forks before the pixel kernel
+ * and runs beside it, and only the run combine waits for the records.  The keys must stay alive and untouched like scratch.
+ * keys_sorted != 0: gsr_surfel_forward_refl has already sorted the keys into THIS scratch (its `scratch` field): no sort here. */
+int gsr_deferred_reflection_backward_keys(const float* normal_view, const float* base_color, const float* refl_strength,
+                                        const float* cam, const float* cubemap, const float* fail_value, uint32_t L,
+                                        int width, int height, const float* g_final, const float* g_refl_color,
+                                        const float* g_normal_world, float* g_normal_view, float* g_base, float* g_strength,
+                                        float* g_cubemap, float* g_fail, float* scratch, size_t scratch_floats,
                                         int accumulate, int async_tail, const float* cubemap_rgba, const uint32_t* sort_keys,
-                                        void* stream);
+                                        int keys_sorted, void* stream);
 int gsr_side_join(void* stream);
 /* Extension: cubemap_rgba (NULL, or 6*L*L*4 floats, 16-byte aligned) receives a texel-interleaved copy [6][L][L][r,g,b,0] of
  * the cubemap, made by the call, from which the pixel kernel gathers each bilinear corner with one 16-byte load instead of
- * three 4-byte ones; hand the same buffer to gsr_deferred_reflection_backward_ex (cubemap_rgba) of the same cubemap, or NULL.
- * sort_keys (NULL, or width*height uint32): receives, per pixel, the sort key of the record the sorted-footprint backward will
- * make for it — the texel id of the upper-left corner of its bilinear footprint, or 6*L*L when the footprint leaves its cube
- * face or the reflection vector is zero; it depends on forward data only (see gsr_deferred_reflection_backward_ex). */
+ * three 4-byte ones; hand the same buffer to gsr_deferred_reflection_backward_ex (cubemap_rgba) of the same cubemap, or NULL. */
 int gsr_deferred_reflection_forward_ex(const float* normal_view, const float* base_color, const float* refl_strength,
+                                       const float* cam, const float* cubemap, const float* fail_value, uint32_t L, int width,
+                                       int height, float* out_final, float* out_refl_color, float* out_normal_world,
+                                       float* cubemap_rgba, void* stream);
+/* ... and with sort_keys (NULL, or width*height uint32): receives, per pixel, the sort key of the record the sorted-footprint backward
+ * will make for it — the texel id of the upper-left corner of its bilinear footprint, or 6*L*L when the footprint leaves its cube
+ * face or the reflection vector is zero; it depends on forward data only (see gsr_deferred_reflection_backward_keys). */
+int gsr_deferred_reflection_forward_keys(const float* normal_view, const float* base_color, const float* refl_strength,
                                        const float* cam, const float* cubemap, const float* fail_value, uint32_t L, int width,
                                        int height, float* out_final, float* out_refl_color, float* out_normal_world,
                                        float* cubemap_rgba, uint32_t* sort_keys, void* stream);

@@ -174,7 +174,8 @@ class HipSurfel:
 class HipGauss:
     """Runs variant G through diff_gaussian_rasterization on cuda:0."""
 
-    def __init__(self, kw, requires_grad=True, scale_modifier=1.0, antialiasing=False, debug=False, prefiltered=False):
+    def __init__(self, kw, requires_grad=True, scale_modifier=1.0, antialiasing=False, debug=False, prefiltered=False, make_sink=None):
+        """make_sink(self) -> (sink dict, accumulate): as HipSurfel."""
         import torch
         from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
         t = to_cuda(kw)
@@ -197,6 +198,8 @@ class HipGauss:
                                            projmatrix=t["projmatrix"], sh_degree=kw["sh_degree"], campos=t["campos"],
                                            prefiltered=prefiltered, debug=debug, antialiasing=antialiasing)
         rast = GaussianRasterizer(st)
+        if make_sink is not None:
+            rast.set_grad_sink(*make_sink(self))
         self.color, self.radii, self.invdepth, self.normal_map, self.refl_map = rast(
             means3D=self.means3D, means2D=self.means2D, opacities=self.opac, shs=self.shs, colors_precomp=self.colors,
             normals=self.normals, refl_strengths=self.refl, scales=self.scales, rotations=self.rots, cov3D_precomp=self.cov)

@@ -1,7 +1,7 @@
 """Development aid (runs here, no GPU): static instruction mix of the tile kernels' hot loops from the compiler's assembly, priced with the
 issue costs measured by tests/microbench/inst_cost.hip (profiles/r02_inst_cost_microbench.txt: 1.1 ns for a VGPR-operand VOP1/2/3, 1.85 ns
 for anything that reads an SGPR / v_min / v_max / v_cmp / v_cndmask / DPP / packed fp32, 3.6 ns for v_exp / v_rcp, per wave64 instruction and
-SIMD at >= 4 waves).  Writes profiles/r03_isa_mix.json stamped with the build digest; bench.py quotes the issue bound of the backward's mix
+SIMD at >= 4 waves).  Writes profiles/r04_isa_mix.json stamped with the build digest; bench.py quotes the issue bound of the backward's mix
 from it while the digest matches (roofline.bound2.issue_bound_of_this_mix).
 The hot loop is taken to be the largest basic block of the kernel (the straight-line pair code; its rare side branches are other blocks)."""
 import collections
@@ -68,7 +68,7 @@ def main():
         out[kernel] = {"block": name, "instructions": len(ins), "mix": dict(mix), "valu": valu, "ns_per_trip_per_simd": round(ns, 1),
                        "avg_ns_per_valu": round(ns / valu, 4)}
         print(kernel, out[kernel])
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_isa_mix.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r04_isa_mix.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,9 @@ def test_library_loads_and_exports_every_declared_symbol(hip_lib_built):
     for n in names:
         assert hasattr(raw, n), f"{n} declared in gsr_hip.h but not exported by libgsr_hip.so"
     assert sorted(names) == sorted(_gsr.EXPORTED)
-    assert _gsr.lib.gsr_version() >= 100
+    # the library and the binding agree on the ABI version the header states (a binding written against another header refuses to load)
+    hdr = open(os.path.join(ROOT, "include", "gsr_hip.h")).read()
+    assert _gsr.lib.gsr_version() == _gsr.GSR_ABI_VERSION == int(re.search(r"#define GSR_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_ctypes_signatures_match_header(hip_lib_built):
@@ -39,6 +41,8 @@ def test_ctypes_signatures_match_header(hip_lib_built):
             return ctypes.POINTER(_gsr.AdamSegment)
         if arg.startswith("const gsr_gather_group*"):
             return ctypes.POINTER(_gsr.GatherGroup)
+        if arg.startswith("const gsr_refl_forward*"):
+            return ctypes.POINTER(_gsr.ReflForward)
         if "*" in arg:
             return ctypes.c_char_p if (arg.startswith("const char") and "uint8" not in arg) else ctypes.c_void_p
         for pre, t in (("float", ctypes.c_float), ("uint32_t", ctypes.c_uint32), ("uint64_t", ctypes.c_uint64), ("size_t", ctypes.c_size_t),
@@ -51,6 +55,17 @@ def test_ctypes_signatures_match_header(hip_lib_built):
         want = [c for c in (ctype(a) for a in args.split(",")) if c is not None]
         have = list(getattr(_gsr.lib, name).argtypes or [])
         assert want == have, name
+
+
+def test_descriptor_structs_match_header(hip_lib_built):
+    """The descriptor struct of the fused rasterize + reflect forward: same fields in the same order as the header."""
+    import _gsr
+    src = open(os.path.join(ROOT, "include", "gsr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for cname, cls in (("gsr_refl_forward", _gsr.ReflForward),):
+        body = re.search(r"typedef struct \{([^}]*)\}\s*%s;" % cname, src, flags=re.S).group(1)
+        fields = [re.sub(r".*[\s\*]", "", f.strip()) for f in body.split(";") if f.strip()]
+        assert fields == [f[0] for f in cls._fields_], cname
 
 
 def test_host_only_entry_points(hip_lib_built):

@@ -213,8 +213,9 @@ def _sharded_tensors(P):
             "cubemap": r(6, 3, 4, 4), "fail": r(3)}
 
 
-def _sharded_worker(rank, world, port, P, steps, out_dir):
-    """reduce-scatter -> Adam on the rank's shard -> all-gather (gsr_dist.ShardedStep) against all-reduce -> full Adam, three steps."""
+def _sharded_worker(rank, world, port, P, steps, out_dir, async_gather=False):
+    """reduce-scatter -> Adam on the rank's shard -> all-gather (gsr_dist.ShardedStep) against all-reduce -> full Adam, three steps.
+    async_gather: the all-gather is left in flight by step() and joined by wait() / the next step()."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -230,16 +231,23 @@ def _sharded_worker(rank, world, port, P, steps, out_dir):
     for k in range(steps):
         gg = torch.Generator().manual_seed(100 * k + rank)
         st.grads.flat.copy_(torch.randn(st.params.total, generator=gg))      # this rank's accumulated view gradients of step k
-        sharded.step()
+        sharded.step(async_gather=async_gather)
+        if async_gather:
+            assert sharded._gather is not None        # in flight; work that does not read the parameters may run here
+            if k % 2 == 0:
+                sharded.wait()                        # explicit join (the next forward) — otherwise the next step() joins
+                assert sharded._gather is None
+    sharded.wait()
     torch.save(st.params.flat.detach().clone(), os.path.join(out_dir, "sharded_%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_reduce_scatter_sharded_adam_all_gather_equals_allreduce_adam(tmp_path):
+@pytest.mark.parametrize("async_gather", [False, True])
+def test_two_rank_reduce_scatter_sharded_adam_all_gather_equals_allreduce_adam(tmp_path, async_gather):
     P, steps, world = 203, 3, 2
-    port = 35500 + (os.getpid() % 2000)
-    mp.spawn(_sharded_worker, args=(world, port, P, steps, str(tmp_path)), nprocs=world, join=True)
+    port = 35500 + (os.getpid() % 2000) + (7 if async_gather else 0)
+    mp.spawn(_sharded_worker, args=(world, port, P, steps, str(tmp_path), async_gather), nprocs=world, join=True)
     got = [torch.load(os.path.join(str(tmp_path), "sharded_%d.pt" % r), weights_only=True) for r in range(world)]
     assert torch.equal(got[0], got[1])                                     # every rank ends with the same, complete parameters
     # serial reference: all-reduce (sum over ranks) then the same Adam over the whole buffer, in one process

@@ -190,8 +190,16 @@ def test_reflection_backward_paths_agree(L, W, H, monkeypatch):
     # sort keys from the forward kernel or from the backward's pixel kernel: the same stable sort of the same keys, bit for bit
     for a, b in zip(grads[True], grads["keys written by the backward"]):
         assert np.array_equal(a, b) or rel_maxnorm(a, b) <= 1e-6     # (rim pixels add with float atomics: arrival order)
-    for a, b in zip(grads[True][:3], grads[False][:3]):
-        assert rel_maxnorm(a, b) <= 1e-4   # same formulas in two kernels; contraction order differs and 1/|n| amplifies it
+    # same formulas in two kernels; contraction order differs and 1/|n| amplifies it.  The NORMAL gradient passes through d(texel
+    # weights)/d(direction), piecewise constant in the direction: a pixel whose float32 direction lands in the neighbouring texel cell in
+    # one of the two kernels differs outright (one of 15 360 at L = 600 since round 4, when the footprint kernel's divisions became
+    # v_rcp): budgeted per pixel as in the float64 comparisons of this file, max-norm for the other two
+    bad = np.abs(grads[True][0] - grads[False][0]).max(axis=0) > 1e-3 * np.abs(grads[False][0]).max()
+    assert bad.mean() <= 2e-3, bad.mean()
+    keep = ~bad
+    assert rel_maxnorm(grads[True][0][:, keep], grads[False][0][:, keep]) <= 2e-4
+    for a, b in zip(grads[True][1:3], grads[False][1:3]):
+        assert rel_maxnorm(a, b) <= 1e-4
     # the two kernels contract the direction arithmetic differently: texel coordinates an ulp apart, times L
     assert rel_maxnorm(grads[True][3], grads[False][3]) <= (1e-4 if L <= 256 else 3e-4)
 

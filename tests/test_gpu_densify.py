@@ -103,3 +103,68 @@ def test_densify_and_prune_matches_reference_sequence(max_screen_size):
     new_state.grads.flat.normal_()
     new_state.optimizer.step()
     assert torch.isfinite(new_state.params.flat).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_densify_and_prune_on_a_sharded_state(world, monkeypatch):
+    """A state built with shard=(rank, N) (gsr_dist.ShardedStep) holds 1 / N of the Adam moments; densification permutes rows of the whole
+    moment buffers.  Every rank of a (here: emulated) group densifies its own state; the all-gather of the moment chunks is stood in for
+    by concatenating the ranks' chunks.  Result: the same parameters as the unsharded state on every rank, and each rank's new moment
+    chunk = that range of the unsharded state's new moments (the two layouts differ only in the padding at the very end)."""
+    import gsr_densify
+    from gsr_densify import DensifyStats, densify_and_prune
+    from gsr_train import GaussianTrainState
+    P = 9001                                            # odd: chunk borders fall inside parameter groups
+    sc, plain, stats, names = _setup(P, 11, -3.2)
+    tensors = {k: plain.p[k].detach().cpu() for k in plain.params.names}
+    shards = [GaussianTrainState(tensors, "cuda", shard=(r, world)) for r in range(world)]
+    total, n = shards[0].params.total, shards[0].params.total // world
+    assert total % (4 * world) == 0 and total >= plain.params.total
+    pad = total - plain.params.total
+    for r, st in enumerate(shards):                     # the same moments as the unsharded state, cut into chunks
+        whole = torch.cat([plain.optimizer.exp_avg, torch.zeros(pad, device="cuda")]), torch.cat([plain.optimizer.exp_avg_sq, torch.zeros(pad, device="cuda")])
+        st.optimizer.exp_avg.copy_(whole[0][r * n:(r + 1) * n])
+        st.optimizer.exp_avg_sq.copy_(whole[1][r * n:(r + 1) * n])
+        st.optimizer.step_count = 17
+        assert st.optimizer.exp_avg.numel() == n
+    rs = np.random.RandomState(5)
+    denom = rs.randint(0, 5, P).astype(np.float32)
+    dw = rs.randint(0, 4, P).astype(np.float32)
+    vals = dict(xyz_gradient_accum=(rs.rand(P) * 8e-4 * denom).astype(np.float32), denom=denom, denom_w=dw, accum_w=(rs.rand(P) * 0.05 * dw).astype(np.float32),
+                max_radii2D=rs.randint(0, 60, P).astype(np.float32))
+    scales = torch.from_numpy(np.log(np.exp(rs.randn(P, 2) * 1.2) * 0.03).astype(np.float32)).cuda()
+
+    def fill(st):
+        s = DensifyStats(P, "cuda")
+        for k, v in vals.items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        with torch.no_grad():
+            st.p["scales"].copy_(scales)
+        return s
+    noise = torch.from_numpy(rs.randn(2 * P, 2).astype(np.float32)).cuda()
+    with pytest.raises(ValueError, match="noise"):
+        densify_and_prune(shards[0], fill(shards[0]), 0.0002, 0.05, torch.zeros(3), 3.0, 20)
+    # the unsharded reference first tells how many split parents there are (the noise has 2 k rows)
+    _, _, info = densify_and_prune(plain, fill(plain), 0.0002, 0.05, torch.zeros(3), 3.0, 20)
+    k = info["split"]
+    ref, _, info = densify_and_prune(plain, fill(plain), 0.0002, 0.05, torch.zeros(3), 3.0, 20, noise=noise[:2 * k])
+    assert info["split"] == k > 20 and info["cloned"] > 20
+    monkeypatch.setattr(gsr_densify, "_whole_moments", lambda state, group: (torch.cat([s.optimizer.exp_avg for s in shards]),
+                                                                             torch.cat([s.optimizer.exp_avg_sq for s in shards])))
+    for r, st in enumerate(shards):
+        new, new_stats, inf = densify_and_prune(st, fill(st), 0.0002, 0.05, torch.zeros(3), 3.0, 20, noise=noise[:2 * k])
+        assert inf == info and new.shard == (r, world) and new.params.total % (4 * world) == 0
+        for kk in new.params.names:
+            assert torch.equal(new.p[kk].detach(), ref.p[kk].detach()), kk
+        a, b = new.optimizer.owned
+        assert b - a == new.params.total // world == new.optimizer.exp_avg.numel()
+        hi = min(b, ref.params.total)
+        assert torch.equal(new.optimizer.exp_avg[:max(0, hi - a)], ref.optimizer.exp_avg[a:hi])
+        assert torch.equal(new.optimizer.exp_avg_sq[:max(0, hi - a)], ref.optimizer.exp_avg_sq[a:hi])
+        assert float(new.optimizer.exp_avg[max(0, hi - a):].abs().max() if b > hi else 0.0) == 0.0
+        # and it steps: this rank's chunk only
+        new.grads.flat.normal_()
+        before = new.params.flat.clone()
+        new.optimizer.step()
+        changed = before != new.params.flat
+        assert bool(changed[a:b].any()) and not bool(changed[:a].any()) and not bool(changed[b:].any())
