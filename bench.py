@@ -302,11 +302,15 @@ def main():
     _gsr.profile_enable(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     R_headline = info["R"]      # (later objects render other views: their instance counts must not leak into the headline's byte counts)
+    n_color = int((scene.grads.view("shs")[:, 0, :] != 0).any(dim=1).sum().item()) if len(views) == 1 else None     # surfels with a colour gradient
     allreduce_ms = float(np.median([a.elapsed_time(b) for a, b in ar_marks])) if ar_marks else 0.0
     # the dominant kernel on its own: a few more steps with the reflection tail on the step's stream (nothing runs beside the tile backward)
     alone_ms = None
     if not args.sync_reflection_tail:
         args.sync_reflection_tail = True
+        for _ in range(2):                     # (the first steps of the other mode size new scratch buffers)
+            step()
+        sync_all()
         _gsr.profile_enable(True)
         for _ in range(5):
             step()
@@ -507,6 +511,25 @@ def main():
             "step_frac_of_measured_ceiling": round(nv * (fwd_bytes + bwdall_bytes + refl_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_MEASURED_GBS, 4),
             "roofline": roof,
         }
+        if n_color is not None:
+            # the other kernels of the step against the HBM roofline, with the bytes each MOVES for this input: the per-Gaussian backward skips the
+            # 192-byte SH row of surfels without a colour gradient (SURVEY.md 8d's 871 B assume every surfel blends; 60 B of per-view outputs
+            # nobody asked for are not written either: 811)
+            st_ms = {k: v[0] / max(1, v[1]) for k, v in stages.items() if v[1] > 0}
+            per_kernel = {}
+            for name, key, upper, moved, why in (
+                    ("surfel_preprocess_kernel", "preprocess", 347 * P, 347 * P, "347 B per surfel (SURVEY.md 8d: inputs 232 + records and per-Gaussian state)"),
+                    ("surfel_preprocess_bwd_kernel", "preprocess_bwd", 871 * P, 369 * P + 192 * n_color,
+                     "what this kernel reads and writes per surfel: 80 (accumulator row) + 12 + 4 + 1 + 16 + 8 (means, radii, clamp flags, rotation, scale) "
+                     "read, 248 written (dL_dmean2D 12, dL_dmean3D 12, dL_dsh 192, dL_dscale 8, dL_drot 16, opacity 4, refl 4) = 369, + the 192-byte SH row "
+                     "of the %d of %d surfels with a colour gradient; SURVEY.md 8d's 871 add 308 B of zero-initialised gradient tensors this design "
+                     "does not have and outputs nobody asked for" % (n_color, P)),
+                    ("surfel_render_fwd_wave_kernel", "render_fwd", 85 * R + (68 + (0 if args.unfused else 44)) * HW, 85 * R + (68 + (0 if args.unfused else 44)) * HW,
+                     "85 B per instance + 68 B per pixel (SURVEY.md 8d)" + ("" if args.unfused else " + 44 B per pixel written by the reflection epilogue")),
+                    ("deferred_refl_bwd_entries_kernel", "refl_bwd", 112 * HW, 112 * HW, "112 B per pixel (SURVEY.md 8d, reflection backward)")):
+                if st_ms.get(key):
+                    per_kernel[name] = roofline_entry(round(st_ms[key], 4), moved, upper, why, pmc_summary(name, P, W, H))
+            out["roofline_other_kernels"] = per_kernel
         out["ranks"] = {"world_size": ranks, "backend": backend or "none", "ms_per_step_per_rank": rank_ms}
         if dist_on:
             out["nccl_ranks"] = ranks if backend == "nccl" else 0   # dist.get_world_size() of the RCCL process group (0: a gloo rehearsal)
@@ -793,25 +816,31 @@ def c5_object(S, dev, steps=20):
         torch.autograd.backward([color, invd, nmap, rmap], [gc, gi, gn, gr])
 
     def timed(n):
-        """n steps, each timed on its own (wall clock, synchronised) with the caching allocator's counters around it"""
-        per_step, allocs = [], []
-        for _ in range(n):
+        """n steps back to back between two synchronisations (ms_per_step: what a training loop pays; a loop that synchronises after every step
+        adds the host's launch latency of the next forward, ~0.15 ms at this size, which no loop has to), one event per step for the per-step
+        list, and the caching allocator's counters around every step (host-side reads, no synchronisation)."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        allocs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(n):
             m0 = torch.cuda.memory_stats(dev)
-            t0 = time.perf_counter()
             step()
-            torch.cuda.synchronize()
-            per_step.append((time.perf_counter() - t0) * 1e3)
+            marks[i + 1].record()
             m1 = torch.cuda.memory_stats(dev)
             d = {k: int(m1.get(k, 0) - m0.get(k, 0)) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free")}
             d["allocated_MB"] = round((m1.get("allocated_bytes.all.allocated", 0) - m0.get("allocated_bytes.all.allocated", 0)) / 1e6, 1)
             allocs.append(d)
-        return per_step, allocs
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n * 1e3
+        return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], allocs
 
     # ---- plain autograd (rounds 1-3): ~2 GB of gradient tensors allocated per step, freed when the next step drops .grad
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    plain_ms, plain_alloc = timed(max(5, steps // 2))
+    plain_wall, plain_ms, plain_alloc = timed(max(5, steps // 2))
     for x in t.values():
         x.grad = None
     plain[0] = False
@@ -821,9 +850,11 @@ def c5_object(S, dev, steps=20):
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    _gsr.profile_enable(True)
-    per_step, sink_alloc = timed(steps)
-    ms = sorted(per_step)[len(per_step) // 2]
+    ms, per_step, sink_alloc = timed(steps)           # no stage timers (each costs two event records: ~0.1 ms per step in all)
+    _gsr.profile_enable(True)                         # the same steps again for the stage table
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
     st = _gsr.profile_collect()
     _gsr.profile_enable(False)
     stage = {k: round(v[0] / steps, 4) for k, v in st.items() if v[1] > 0}
@@ -833,8 +864,11 @@ def c5_object(S, dev, steps=20):
     n_color = int((fg.view("shs")[:, 0, :] != 0).any(dim=1).sum().item())
     kernels = {}
     for name, key, upper, moved, why in (
-            ("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P, 639 * P - 192 * (P - n_color),
-             "639 B per Gaussian (SURVEY.md 8d) minus the 192-byte SH row of the %d of %d Gaussians whose colour gradient is zero (not read)" % (P - n_color, P)),
+            ("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P, 405 * P + 192 * n_color,
+             "what this kernel reads and writes per Gaussian: 64 (accumulator row) + 12 + 4 + 24 + 4 + 12 + 16 + 1 (means, radii, cov3D, opacity, scale, "
+             "rotation, clamp flags) read, 268 written (dL_dmean2D_pixels 12, dL_dnormal 12, opacity 4, refl 4, inverse depth 4, dL_dmean3D 12, dL_dsh 192, "
+             "dL_dscale 12, dL_drot 16) = 405, + the 192-byte SH row of the %d of %d Gaussians with a colour gradient; SURVEY.md 8d's 639 count "
+             "every SH row and outputs nobody asked for" % (n_color, P)),
             ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW, 124 * R[0] + 40 * HW, "124 B per instance + 40 B per pixel (SURVEY.md 8d)")):
         if stage.get(key):
             pmc = pmc_summary(name, P, W, H, PMC_FILE_C5)
@@ -843,12 +877,14 @@ def c5_object(S, dev, steps=20):
     torch.cuda.empty_cache()
     return {"workload": "C5: 5M Gaussians, 1920x1080, SH deg 3, variant G, anti-aliasing + inverse-depth backward, fwd+bwd; parameter gradients through "
                         "gradient sinks into one flat buffer (as the C3 step)", "num_rendered": R[0],
-            "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps, "stage_ms_per_step": stage,
+            "ms_per_step": round(ms, 4), "ms_per_step_all": [round(x, 3) for x in per_step], "steps": steps,
+            "timing": "ms_per_step: wall clock over the steps back to back between two synchronisations; ms_per_step_all: one event per step",
+            "stage_ms_per_step": stage,
             "kernel_sum_ms": round(sum(stage.values()), 4), "step_over_kernel_sum": round(ms / max(1e-9, sum(stage.values())), 4),
             "allocator_per_step": {"what": "torch.cuda.memory_stats() deltas around each synchronised step (caching allocator): num_device_alloc > 0 or "
                                            "num_alloc_retries > 0 inside the loop means the step went to hipMalloc / freed cached blocks and retried",
                                    "sinks": sink_alloc, "plain_autograd": plain_alloc},
-            "plain_autograd": {"ms_per_step": round(sorted(plain_ms)[len(plain_ms) // 2], 4), "ms_per_step_all": [round(x, 3) for x in plain_ms],
+            "plain_autograd": {"ms_per_step": round(plain_wall, 4), "ms_per_step_all": [round(x, 3) for x in plain_ms],
                                "what": "the same step with the ~2 GB of parameter gradients allocated by autograd every step (rounds 1-3)"},
             "roofline": kernels}
 

@@ -5,7 +5,8 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "surfel_preprocess_kernel" in r["Kernel_Name"]]
+first = sys.argv[3] if len(sys.argv) > 3 else "surfel_preprocess_kernel"      # (C5: gauss_preprocess_kernel)
+idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 steps = [(a, b) for a, b in zip(idx, idx[1:]) if any("render_bwd" in r["Kernel_Name"] for r in rows[a:b])]
 a, b = steps[min(len(steps) - 1, int(sys.argv[2]) if len(sys.argv) > 2 else 4)]
 t0 = int(rows[a]["Start_Timestamp"])
