@@ -339,8 +339,17 @@ deferred_refl_bwd_kernel(const float* __restrict__ normal_view, const float* __r
 // The same backward for the sorted-footprint path (`binned` in the C ABI), one lane per pixel: nothing here needs the four lanes of the quad version (they
 // exist to pair the texel atomics), so the index math runs once per pixel instead of four times.  The per-pixel body is
 // refl_backward_pixel (gsr_refl.hpp), which the tile backward of the surfel rasterizer also runs as its prologue (fused path).
+// Workgroup size 512 (round 4; no LDS, no barrier: any multiple of 64 is correct).  Together with 512-thread workgroups in the key sort
+// that runs beside this kernel on the side stream (REFL_SORT_BS): a 1024-thread sort workgroup needs sixteen free wave slots on one CU at
+// once and never got them while this kernel was dispatching 256-thread workgroups — the sort's 8-us histogram took the kernel's whole 60 us,
+// its first pass started when this kernel ended and the tile backward then waited for the gate in front of the second pass.  With 512 / 512
+// the two interleave: histogram 13 us and first pass 43 us beside this kernel (62 -> 81 us), gate open before it ends; tile backward starts
+// 93 us after this kernel instead of 110 (profiles/r04_trace_c3_step_refl_sort_512.txt; three interleaved A/B runs: -8 ... -18 us per step).
+#ifndef ENTRIES_BS
+#define ENTRIES_BS 512
+#endif
 template <bool RGBA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ENTRIES_BS)
 deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const float* __restrict__ base, const float* __restrict__ strength,
                                  const float* __restrict__ cam, const float* __restrict__ cubemap, const float4* __restrict__ rgba,
                                  const float* __restrict__ fail_value, int L,
@@ -350,8 +359,8 @@ deferred_refl_bwd_entries_kernel(const float* __restrict__ normal_view, const fl
                                  ReflFootprint* __restrict__ footprints, uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_fwd, uint32_t no_key,
                                  void* sort_clear, size_t sort_clear_bytes) {
 	const size_t HW = (size_t)W * H;
-	const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
-	sort_clear_region(sort_clear, sort_clear_bytes, pix, (size_t)gridDim.x * 256u);   // look-back state of the sort that follows
+	const size_t pix = (size_t)blockIdx.x * ENTRIES_BS + threadIdx.x;
+	sort_clear_region(sort_clear, sort_clear_bytes, pix, (size_t)gridDim.x * ENTRIES_BS);   // look-back state of the sort that follows
 	const bool live = pix < HW;
 	const size_t p = live ? pix : 0;
 	const int py = (int)(p / W), px = (int)(p - (size_t)py * W);
@@ -584,12 +593,20 @@ struct ReflScratch {
 #ifndef REFL_SMALL_SORT
 #define REFL_SMALL_SORT 1
 #endif
+// Shape of the 9-bit sort (L = 128).  Round 4: 512 x 16 instead of 1024 x 8 — the same 8192 pairs per workgroup, but a workgroup that finds
+// room beside the backward's pixel kernel (see ENTRIES_BS); alone on the chip the two shapes are within 2 us of each other.
+#ifndef REFL_SORT_BS
+#define REFL_SORT_BS 512
+#endif
+#ifndef REFL_SORT_IPT
+#define REFL_SORT_IPT 16
+#endif
 static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, const uint32_t* keys_in, uint32_t* keys_out, uint32_t* pix_out, size_t n, hipStream_t stream,
                             bool pre_cleared = false, bool small = false, hipEvent_t gate = nullptr) {
 	rocprim::counting_iterator<uint32_t> pix_in(0);
 	if (temp == nullptr) {   // size query: the largest of the drivers' needs (neither the runtime switch nor the stream a tail runs on changes a scratch size)
 		size_t own = 0, pub = 0, sm = 0;
-		if (key_bits > 16 && key_bits <= 18) (void)onesweep_sort_pairs<1024, 8, 9>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
+		if (key_bits > 16 && key_bits <= 18) (void)onesweep_sort_pairs<REFL_SORT_BS, REFL_SORT_IPT, 9>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		else if (key_bits > 18 && key_bits <= 20) (void)onesweep_sort_pairs<1024, 8, 10>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		else (void)onesweep_sort_pairs<1024, 8, 8>(nullptr, own, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
 		(void)onesweep_sort_pairs<256, 8, 8>(nullptr, sm, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream);
@@ -606,14 +623,14 @@ static hipError_t refl_sort(void* temp, size_t& bytes, int key_bits, const uint3
 	if (small)
 		return onesweep_sort_pairs<256, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 	if (key_bits > 16 && key_bits <= 18)
-		return onesweep_sort_pairs<1024, 8, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
+		return onesweep_sort_pairs<REFL_SORT_BS, REFL_SORT_IPT, 9>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 	if (key_bits > 18 && key_bits <= 20)
 		return onesweep_sort_pairs<1024, 8, 10>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 	return onesweep_sort_pairs<1024, 8, 8>(temp, bytes, keys_in, keys_out, pix_in, pix_out, n, 0u, (unsigned)key_bits, stream, pre_cleared, nullptr, gate);
 }
 static size_t refl_sort_cleared_bytes(int key_bits, size_t n, bool small) {
 	if (small) return onesweep_cleared_bytes<256, 8, 8>(n, 0u, (unsigned)key_bits);
-	if (key_bits > 16 && key_bits <= 18) return onesweep_cleared_bytes<1024, 8, 9>(n, 0u, (unsigned)key_bits);
+	if (key_bits > 16 && key_bits <= 18) return onesweep_cleared_bytes<REFL_SORT_BS, REFL_SORT_IPT, 9>(n, 0u, (unsigned)key_bits);
 	if (key_bits > 18 && key_bits <= 20) return onesweep_cleared_bytes<1024, 8, 10>(n, 0u, (unsigned)key_bits);
 	return onesweep_cleared_bytes<1024, 8, 8>(n, 0u, (unsigned)key_bits);
 }
@@ -906,16 +923,16 @@ extern "C" int gsr_deferred_reflection_backward_keys(const float* normal_view, c
 	if (rc < 0) return rc;
 	{
 		StageTimer st_(GSR_STAGE_REFL_BWD, stream);      // the pixel kernel; the texel-gradient tail is GSR_STAGE_REFL_BWD_TAIL
-		const unsigned egrid = (unsigned)((HW + 255) / 256);
+		const unsigned egrid = (unsigned)((HW + ENTRIES_BS - 1) / ENTRIES_BS);
 		ReflFootprint* fp = static_cast<ReflFootprint*>(t.footprints);
 		if (cubemap_rgba && ((uintptr_t)cubemap_rgba & 15) == 0)     // the texel-interleaved copy the forward made (same cubemap)
-			deferred_refl_bwd_entries_kernel<true><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
+			deferred_refl_bwd_entries_kernel<true><<<egrid, ENTRIES_BS, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap,
 			                                                                 reinterpret_cast<const float4*>(cubemap_rgba), fail_value, (int)L, width, height, g_final,
 			                                                                 g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, t.fail_acc, t.staging, fp,
 			                                                                 t.keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : t.sort_temp,
 			                                                                 sort_keys ? 0 : t.clear_bytes[1]);
 		else
-			deferred_refl_bwd_entries_kernel<false><<<egrid, 256, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
+			deferred_refl_bwd_entries_kernel<false><<<egrid, ENTRIES_BS, 0, stream>>>(normal_view, base_color, refl_strength, cam, cubemap, nullptr, fail_value, (int)L, width,
 			                                                                  height, g_final, g_refl_color, g_normal_world, g_normal_view, g_base, g_strength, t.fail_acc,
 			                                                                  t.staging, fp, t.keys_in, sort_keys, (uint32_t)ntex, sort_keys ? nullptr : t.sort_temp,
 			                                                                  sort_keys ? 0 : t.clear_bytes[1]);
