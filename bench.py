@@ -284,12 +284,22 @@ def main():
         step()
     # the timed region: exactly K steps between two barrier + synchronize brackets, nothing else on the stream (no events, no
     # per-stage timers: every hipEventRecord costs a ~5-10 us bubble between two kernels, 0.1 ms per step when every stage has two)
+    import gc as pygc
+    gc_events, gc_t = [], [0.0]
+
+    def on_gc(phase, info):    # collections of the Python garbage collector inside the timed region are reported, not hidden (`python_gc_in_timed_region`)
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_events.append({"generation": info.get("generation"), "ms": round((time.perf_counter() - gc_t[0]) * 1e3, 2)})
+    pygc.callbacks.append(on_gc)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
     sync_all()
     dt = time.perf_counter() - t0
+    pygc.callbacks.remove(on_gc)
     # the same K steps again, instrumented: one event per step (percentiles) and the library's per-stage hipEvent timers
     _gsr.profile_enable(True)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -499,6 +509,7 @@ def main():
                        "reflection": "two nodes: rasterizer, then deferred_reflection (--unfused)" if args.unfused else
                                      "fused: the deferred reflection's pixel code runs inside the rasterizer's tile kernels (rasterize_reflect)"},
             "step_ms": percentiles(step_ms),
+            "python_gc_in_timed_region": gc_events,
             "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4), "forward_step_ms": percentiles(fwd_step_ms),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
             "instrumented": "step_ms and stage_ms_per_view come from a second pass of the same K steps with one event per step and the library's "
@@ -518,7 +529,7 @@ def main():
             st_ms = {k: v[0] / max(1, v[1]) for k, v in stages.items() if v[1] > 0}
             per_kernel = {}
             for name, key, upper, moved, why in (
-                    ("surfel_preprocess_kernel", "preprocess", 347 * P, 347 * P, "347 B per surfel (SURVEY.md 8d: inputs 232 + records and per-Gaussian state)"),
+                    ("surfel_preprocess_kernel", "preprocess", 347 * P, 339 * P, "339 B per surfel (SURVEY.md 8d's 347: inputs 232 + records and per-Gaussian state, less the 8-byte means2D array that is no longer kept beside the record)"),
                     ("surfel_preprocess_bwd_kernel", "preprocess_bwd", 871 * P, 369 * P + 192 * n_color,
                      "what this kernel reads and writes per surfel: 80 (accumulator row) + 12 + 4 + 1 + 16 + 8 (means, radii, clamp flags, rotation, scale) "
                      "read, 248 written (dL_dmean2D 12, dL_dmean3D 12, dL_dsh 192, dL_dscale 8, dL_drot 16, opacity 4, refl 4) = 369, + the 192-byte SH row "
@@ -819,14 +830,26 @@ def c5_object(S, dev, steps=20):
         """n steps back to back between two synchronisations (ms_per_step: what a training loop pays; a loop that synchronises after every step
         adds the host's launch latency of the next forward, ~0.15 ms at this size, which no loop has to), one event per step for the per-step
         list, and the caching allocator's counters around every step (host-side reads, no synchronisation)."""
+        import gc as pygc
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-        allocs = []
+        allocs, host_ms, gc_events, cur = [], [], [], [0, 0.0]
+
+        def on_gc(phase, info):       # a collection of the Python garbage collector inside the loop: which step, which generation, how long
+            if phase == "start":
+                cur[1] = time.perf_counter()
+            else:
+                gc_events.append({"step": cur[0], "generation": info.get("generation"), "ms": round((time.perf_counter() - cur[1]) * 1e3, 2),
+                                  "collected": info.get("collected")})
+        pygc.callbacks.append(on_gc)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         marks[0].record()
         for i in range(n):
+            cur[0] = i
             m0 = torch.cuda.memory_stats(dev)
+            h0 = time.perf_counter()
             step()
+            host_ms.append(round((time.perf_counter() - h0) * 1e3, 3))
             marks[i + 1].record()
             m1 = torch.cuda.memory_stats(dev)
             d = {k: int(m1.get(k, 0) - m0.get(k, 0)) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free")}
@@ -834,13 +857,14 @@ def c5_object(S, dev, steps=20):
             allocs.append(d)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / n * 1e3
-        return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], allocs
+        pygc.callbacks.remove(on_gc)
+        return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], allocs, host_ms, gc_events
 
     # ---- plain autograd (rounds 1-3): ~2 GB of gradient tensors allocated per step, freed when the next step drops .grad
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    plain_wall, plain_ms, plain_alloc = timed(max(5, steps // 2))
+    plain_wall, plain_ms, plain_alloc, plain_host, plain_gc = timed(max(5, steps // 2))
     for x in t.values():
         x.grad = None
     plain[0] = False
@@ -850,7 +874,7 @@ def c5_object(S, dev, steps=20):
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    ms, per_step, sink_alloc = timed(steps)           # no stage timers (each costs two event records: ~0.1 ms per step in all)
+    ms, per_step, sink_alloc, host_ms, gc_events = timed(steps)           # no stage timers (each costs two event records: ~0.1 ms per step in all)
     _gsr.profile_enable(True)                         # the same steps again for the stage table
     for _ in range(steps):
         step()
@@ -864,10 +888,10 @@ def c5_object(S, dev, steps=20):
     n_color = int((fg.view("shs")[:, 0, :] != 0).any(dim=1).sum().item())
     kernels = {}
     for name, key, upper, moved, why in (
-            ("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P, 405 * P + 192 * n_color,
-             "what this kernel reads and writes per Gaussian: 64 (accumulator row) + 12 + 4 + 24 + 4 + 12 + 16 + 1 (means, radii, cov3D, opacity, scale, "
-             "rotation, clamp flags) read, 268 written (dL_dmean2D_pixels 12, dL_dnormal 12, opacity 4, refl 4, inverse depth 4, dL_dmean3D 12, dL_dsh 192, "
-             "dL_dscale 12, dL_drot 16) = 405, + the 192-byte SH row of the %d of %d Gaussians with a colour gradient; SURVEY.md 8d's 639 count "
+            ("gauss_preprocess_bwd_kernel", "preprocess_bwd", 639 * P, 381 * P + 192 * n_color,
+             "what this kernel reads and writes per Gaussian: 64 (accumulator row) + 12 + 4 + 4 + 12 + 16 + 1 (means, radii, opacity, scale, "
+             "rotation, clamp flags; the 3D covariance is recomputed, not read) read, 268 written (dL_dmean2D_pixels 12, dL_dnormal 12, opacity 4, refl 4, inverse depth 4, dL_dmean3D 12, dL_dsh 192, "
+             "dL_dscale 12, dL_drot 16) = 381, + the 192-byte SH row of the %d of %d Gaussians with a colour gradient; SURVEY.md 8d's 639 count "
              "every SH row and outputs nobody asked for" % (n_color, P)),
             ("gauss_render_bwd_wave_kernel", "render_bwd", 124 * R[0] + 40 * HW, 124 * R[0] + 40 * HW, "124 B per instance + 40 B per pixel (SURVEY.md 8d)")):
         if stage.get(key):
@@ -883,10 +907,22 @@ def c5_object(S, dev, steps=20):
             "kernel_sum_ms": round(sum(stage.values()), 4), "step_over_kernel_sum": round(ms / max(1e-9, sum(stage.values())), 4),
             "allocator_per_step": {"what": "torch.cuda.memory_stats() deltas around each synchronised step (caching allocator): num_device_alloc > 0 or "
                                            "num_alloc_retries > 0 inside the loop means the step went to hipMalloc / freed cached blocks and retried",
-                                   "sinks": sink_alloc, "plain_autograd": plain_alloc},
+                                   "sinks": alloc_summary(sink_alloc), "plain_autograd": alloc_summary(plain_alloc)},
+            "host_ms_per_step": host_ms, "python_gc_during_timed_steps": gc_events,
+            "outliers": {"what": "a step far above the others: host_ms_per_step says whether the HOST was held up inside that step's calls (then "
+                                 "python_gc_during_timed_steps / allocator_per_step name the cause) or only the GPU time between its events grew",
+                         "steps_above_1.5x_median": [i for i, x in enumerate(per_step) if x > 1.5 * sorted(per_step)[len(per_step) // 2]]},
             "plain_autograd": {"ms_per_step": round(plain_wall, 4), "ms_per_step_all": [round(x, 3) for x in plain_ms],
                                "what": "the same step with the ~2 GB of parameter gradients allocated by autograd every step (rounds 1-3)"},
             "roofline": kernels}
+
+
+def alloc_summary(rows):
+    """Per-step allocator deltas, compressed: the bytes served per step and the steps in which the caching allocator went to the device."""
+    mb = sorted(r["allocated_MB"] for r in rows)
+    return {"allocated_MB_per_step_median": mb[len(mb) // 2] if mb else None,
+            "steps_with_device_alloc_free_or_retry": [dict(step=i, **{k: v for k, v in r.items() if k != "allocated_MB"}) for i, r in enumerate(rows)
+                                                       if r["num_alloc_retries"] or r["num_device_alloc"] or r["num_device_free"]]}
 
 
 def roofline_entry(ms, moved, upper, why, pmc):

@@ -177,7 +177,6 @@ GeomState carve_geom(void* buf, size_t P, int rec_f4, int aux_floats, int acc_fl
 	Carver c(buf);
 	GeomState g;
 	g.depths = c.take<float>(P);
-	g.means2D = c.take<float2>(P);
 	g.rect = c.take<uint32_t>(2 * P);
 	g.tiles_touched = c.take<uint32_t>(P);
 	g.point_offsets = c.take<uint32_t>(P);
@@ -744,7 +743,7 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	const size_t HW = (size_t)width * height, tiles = (size_t)tiles_x * tiles_y;
 	const int rec_f4 = variant == 0 ? 5 : 4;
 	const int stride = rec_f4 * 4;
-	GeomState g = carve_geom((void*)geom_buffer, P, rec_f4, variant == 0 ? 0 : 6, variant == 0 ? 20 : 16, scan_temp_bytes(P), nullptr);
+	GeomState g = carve_geom((void*)geom_buffer, P, rec_f4, 0, variant == 0 ? 20 : 16, scan_temp_bytes(P), nullptr);
 	ImageState im = carve_image((void*)image_buffer, HW, tiles, variant == 0 ? 3 : 1, variant == 0 ? 2 : 1, nullptr);
 	BinningState b = carve_binning((void*)binning_buffer, R, tiles, 0, nullptr);
 	auto d2d = [&](const void* src, size_t bytes) -> int {
@@ -760,7 +759,8 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 	};
 	std::string n(name);
 	if (n == "depths") return d2d(g.depths, (size_t)P * 4);
-	if (n == "means2D") return d2d(g.means2D, (size_t)P * 8);
+	if (n == "means2D") return gather(0, 2);     // the first two floats of the render record of both variants (not kept as an array of its own since round 4)
+
 	if (n == "tiles_touched") return d2d(g.tiles_touched, (size_t)P * 4);
 	if (n == "cull") return d2d(g.bbox, (size_t)P * 32);   // two float4 per Gaussian (see cull_hit)
 	if (n == "point_offsets") {   // not kept by the forward (it only needs the total): inclusive scan of tiles_touched on demand
@@ -791,7 +791,7 @@ extern "C" int gsr_debug_fetch(int variant, const char* name, int P, int R, int 
 		return variant == 0 ? pick({12, 13, 14, 11}) : gather(2, 4);
 	}
 	if (n == "transMat" && variant == 0) return pick({2, 4, 6, 3, 5, 7, 8, 9, 10});
-	if (n == "cov3D" && variant == 1) return d2d(g.aux, (size_t)P * 6 * 4);
+	if (n == "cov3D" && variant == 1) { set_error("gsr_debug_fetch: the 3D covariance is not kept by the forward (round 4: the backward recomputes it)"); return GSR_E_INVALID; }
 	if (n == "point_list") return d2d(b.point_list, (size_t)R * 4);
 	if (n == "keys") {   // reference-format sorted keys, rebuilt (the product path sorts tile ids only)
 		if (R == 0) return 0;

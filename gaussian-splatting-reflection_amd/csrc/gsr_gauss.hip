@@ -151,7 +151,6 @@ gauss_preprocess_one(int idx, int D, int M, const float* __restrict__ means, con
 	}
 	g.depths[idx] = pvz;
 	radii[idx] = f2i(my_radius);
-	g.means2D[idx] = make_float2(pix_x, pix_y);
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
 	float4* rec = o;
@@ -202,7 +201,8 @@ gauss_preprocess_kernel(int P, int D, int M, const float* __restrict__ means, co
 	const int ng = min(64, P - g0);
 	wave_store_rows4<G_REC_F4, false>(so, o, g.rec + (size_t)g0 * G_REC_F4, G_REC_F4, 0, ng, lane);
 	wave_store_rows4<2, false>(so, o + G_REC_F4, g.bbox + (size_t)g0 * 2, 2, 0, ng, lane);
-	if (cov3D_precomp == nullptr) wave_store_rows<6, false>(reinterpret_cast<float*>(so), cov3D, g.aux + (size_t)g0 * 6, ng, lane);
+	// (round 4: the 3D covariance is not kept for the backward any more — 24 bytes written here and read there per Gaussian, for a value
+	// that the backward recomputes from the scale and rotation rows it reads anyway, with the same instructions: cov3d_from_scale_rot)
 }
 
 // Per (pixel, Gaussian) falloff shared VERBATIM by the forward and backward tile kernels: the backward
@@ -571,8 +571,13 @@ gauss_preprocess_bwd_kernel(int P, int D, int M, const float* __restrict__ means
 	const float mx = means[3 * idx], my = means[3 * idx + 1], mz = means[3 * idx + 2];
 	if (visible) {
 		// ---- computeCov2DCUDA
-		const float* cov3D = cov3Ds + 6 * idx;
-		const float c3[6] = {cov3D[0], cov3D[1], cov3D[2], cov3D[3], cov3D[4], cov3D[5]};
+		float c3[6];
+		if (cov3Ds != nullptr) {       // supplied by the caller (cov3D_precomp)
+#pragma unroll
+			for (int i = 0; i < 6; i++) c3[i] = cov3Ds[6 * idx + i];
+		} else {                       // the forward's value, recomputed (no contraction in there: the same bits)
+			cov3d_from_scale_rot(scales + 3 * idx, scale_modifier, rotations + 4 * idx, c3);
+		}
 		const Cov2DCtx k = cov2d_ctx(mx, my, mz, cam);
 		const float x_grad_mul = (k.txtz < -k.limx || k.txtz > k.limx) ? 0.f : 1.f;
 		const float y_grad_mul = (k.tytz < -k.limy || k.tytz > k.limy) ? 0.f : 1.f;
@@ -774,12 +779,12 @@ extern "C" int gsr_gauss_forward(gsr_alloc_fn alloc, void* alloc_user, int P, in
 
 	size_t geom_bytes = 0, img_bytes = 0;
 	const size_t scan_bytes = scan_temp_bytes(P);
-	carve_geom(nullptr, P, G_REC_F4, 6, G_ACC_F, scan_bytes, &geom_bytes);
+	carve_geom(nullptr, P, G_REC_F4, 0, G_ACC_F, scan_bytes, &geom_bytes);
 	carve_image(nullptr, HW, ntiles, 1, 1, &img_bytes);
 	void* gbuf = alloc(alloc_user, GSR_BUF_GEOM, geom_bytes);
 	void* ibuf = alloc(alloc_user, GSR_BUF_IMAGE, img_bytes);
 	if (!gbuf || !ibuf) { set_error("workspace allocation failed (%zu / %zu bytes)", geom_bytes, img_bytes); return GSR_E_ALLOC; }
-	GeomState geom = carve_geom(gbuf, P, G_REC_F4, 6, G_ACC_F, scan_bytes, nullptr);
+	GeomState geom = carve_geom(gbuf, P, G_REC_F4, 0, G_ACC_F, scan_bytes, nullptr);
 	ImageState img = carve_image(ibuf, HW, ntiles, 1, 1, nullptr);
 
 	if (prefiltered) GSR_HIP_CHECK(hipMemsetAsync(geom.flags, 0, 4 * sizeof(int), stream));   // the flag is only written and read then
@@ -835,7 +840,7 @@ extern "C" int gsr_gauss_backward_accum(int P, int D, int M, int R, const float*
 	const size_t HW = (size_t)width * height;
 	const int tiles_x = (width + 15) / 16, tiles_y = (height + 15) / 16;
 	const int ntiles = tiles_x * tiles_y;
-	GeomState geom = carve_geom(geom_buffer, P, G_REC_F4, 6, G_ACC_F, scan_temp_bytes(P), nullptr);
+	GeomState geom = carve_geom(geom_buffer, P, G_REC_F4, 0, G_ACC_F, scan_temp_bytes(P), nullptr);
 	ImageState img = carve_image(image_buffer, HW, ntiles, 1, 1, nullptr);
 	BinningState bin = carve_binning(binning_buffer, R, ntiles, 0, nullptr);
 
@@ -856,7 +861,7 @@ extern "C" int gsr_gauss_backward_accum(int P, int D, int M, int R, const float*
 		GSR_LAUNCH_CHECK(debug, stream);
 	}
 	const GaussCam cam = make_cam(viewmatrix, projmatrix, cam_pos, width, height, tan_fovx, tan_fovy);
-	const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : geom.aux;
+	const float* cov3D_ptr = cov3D_precomp;      // NULL: the kernel recomputes it from scales / rotations
 { StageTimer st_(GSR_STAGE_PREPROCESS_BWD, stream);
 	auto kern = accumulate ? gauss_preprocess_bwd_kernel<true> : gauss_preprocess_bwd_kernel<false>;
 	kern<<<(P + 255) / 256, 256, 0, stream>>>(P, D, M, means3D, radii, shs, geom.clamped, opacities, scales, rotations,

@@ -73,7 +73,6 @@ struct Carver {
 // kernels: REC_F4 float4 per Gaussian (G: 4 = 64 B, S: 5 = 80 B), written by preprocess.
 struct GeomState {
 	float* depths;           // P        view-space z (sort key low word)
-	float2* means2D;         // P        pixel-space centre
 	uint32_t* rect;          // P        packed tile rect: xmin | ymin<<8 ... see pack_rect (2 words)
 	uint32_t* tiles_touched; // P
 	uint32_t* point_offsets; // P        inclusive scan

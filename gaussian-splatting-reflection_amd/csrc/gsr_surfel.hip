@@ -212,7 +212,6 @@ surfel_preprocess_one(int idx, int D, int M, const float* __restrict__ means, co
 	}
 	g.depths[idx] = pvz;
 	radii[idx] = f2i(radius);
-	g.means2D[idx] = make_float2(pxi, pyi);
 	g.rect[2 * idx] = x0 | (y0 << 16);
 	g.rect[2 * idx + 1] = x1 | (y1 << 16);
 	const float maskv = (env_scope_mask != nullptr && env_scope_mask[idx]) ? 1.0f : 0.0f;

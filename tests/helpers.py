@@ -220,7 +220,7 @@ class HipGauss:
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         spec = {"depths": (torch.float32, (P,)), "means2D": (torch.float32, (P, 2)), "tiles_touched": (torch.int32, (P,)),
                 "point_offsets": (torch.int32, (P,)), "clamped": (torch.uint8, (P, 3)), "rgb": (torch.float32, (P, 3)),
-                "geom4": (torch.float32, (P, 4)), "cov3D": (torch.float32, (P, 6)), "point_list": (torch.int32, (R,)),
+                "geom4": (torch.float32, (P, 4)), "point_list": (torch.int32, (R,)),
                 "keys": (torch.int64, (R,)), "ranges": (torch.int32, (tiles, 2)), "final_T": (torch.float32, (1, H, W)),
                 "n_contrib": (torch.int32, (1, H, W))}[name]
         return _gsr.debug_fetch(1, name, P, R, W, H, geom, binning, img, spec[0], spec[1]).cpu().numpy()
