@@ -105,11 +105,25 @@ def percentiles(ms):
     return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(float(a[0]), 4), "max": round(float(a[-1]), 4)}
 
 
+def settle(step, args, views_per_step=1):
+    """Untimed steps in front of a loop's warm-up (see --settle-steps): a fixed count (every rank runs the same number of collectives), scaled
+    down for loops whose step is a batch of views.  Returns how many."""
+    n = -(-max(0, int(getattr(args, "settle_steps", 0))) // max(1, views_per_step))
+    for _ in range(n):
+        step()
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-steps", type=int, default=24,
+                    help="untimed steps IN FRONT of the --warmup steps of every timed loop: after an idle period (scene set-up, a host-side "
+                         "collect) the first ~12 launches run up to 15 %% slower (profiles/r04_clock_ramp_tile_backward.txt: the tile backward takes "
+                         "808, 843, 860, 816, 813, 804, 783, 767, 758, 754, 736, 736, 722 us, then 720-735); 0 = off.  Reported as `settle_steps`; "
+                         "the timed region is still exactly --steps steps behind --warmup steps")
     ap.add_argument("--views", type=int, default=0, help="views per step over all ranks (default: 1 on one GPU = C3, 8 on several = C4)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
@@ -184,7 +198,7 @@ def main():
     if args.only_c5:
         if world != 1:
             raise SystemExit("bench: --only-c5 is a single-GPU run")
-        print(json.dumps(c5_object(S, dev, steps=max(5, args.steps))), flush=True)
+        print(json.dumps(c5_object(S, dev, steps=max(5, args.steps), settle_steps=args.settle_steps // 2)), flush=True)
         return
 
     if os.environ.get("GSR_DEV"):
@@ -280,6 +294,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle_steps = settle(step, args, len(my_views))
     for _ in range(args.warmup):
         step()
     # the timed region: exactly K steps between two barrier + synchronize brackets, nothing else on the stream (no events, no
@@ -321,6 +336,7 @@ def main():
         for _ in range(2):                     # (the first steps of the other mode size new scratch buffers)
             step()
         sync_all()
+        settle(step, args, len(my_views))      # (the collect above left the GPU idle: without this the five launches below are the slow ones of the ramp)
         _gsr.profile_enable(True)
         for _ in range(5):
             step()
@@ -392,6 +408,7 @@ def main():
         pass for the stage table (per view)."""
         for _ in range(2):
             step_into(sc.grads, lambda b: b.all_reduce(), batch=batch, sc=sc)
+        settle(lambda: step_into(sc.grads, lambda b: b.all_reduce(), batch=batch, sc=sc), args, len(batch))
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for _ in range(nb):
@@ -496,7 +513,7 @@ def main():
                     "source": "profiles/r04_isa_mix.json (tests/isa_mix.py, same build digest) x SQ_INSTS_VALU of the PMC pass"}
         out = {
             "metric": "train_step_views_per_s (fwd+bwd, 1e6 Gaussians @1080p, surfel rasterizer + reflection path)",
-            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if dist_on else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C4: batch of %d views of the C3 scene per step, sharded over the GPUs, one RCCL all-reduce of the per-Gaussian + "
@@ -558,7 +575,7 @@ def main():
             out["full_train_step"] = full
         if not args.no_c5 and world == 1:
             torch.cuda.empty_cache()
-            out["c5"] = c5_object(S, dev)
+            out["c5"] = c5_object(S, dev, settle_steps=args.settle_steps // 2)
         if not args.no_dropin and world == 1:
             torch.cuda.empty_cache()
             out["dropin"] = dropin_object(args, S, dev)
@@ -669,6 +686,7 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
             st.optimizer.step()
         return loss
 
+    settle(lambda: full_step(1), args, len(views))
     for i in range(args.warmup):
         full_step(i + 1)
     sync_all()
@@ -758,6 +776,7 @@ def dropin_object(args, S, dev):
         return loss
 
     K, Wm = args.steps, args.warmup
+    settle(train_step, args)
     for _ in range(Wm):
         train_step()
     torch.cuda.synchronize()
@@ -789,7 +808,7 @@ def dropin_object(args, S, dev):
             "render_fast_calls": n}
 
 
-def c5_object(S, dev, steps=20):
+def c5_object(S, dev, steps=20, settle_steps=12):
     """BASELINE config C5 on this GPU: 5e6 Gaussians, 1920x1080, SH 3, the 3DGS rasterizer (variant G) with anti-aliasing and the
     inverse-depth (depth-regularisation) backward enabled, forward + backward.  Round 4: the parameter gradients go through gradient
     sinks into one flat buffer as in the C3 step (variant G has them now); the plain-autograd form of rounds 1-3 is timed beside it
@@ -861,7 +880,7 @@ def c5_object(S, dev, steps=20):
         return wall, [marks[i].elapsed_time(marks[i + 1]) for i in range(n)], allocs, host_ms, gc_events
 
     # ---- plain autograd (rounds 1-3): ~2 GB of gradient tensors allocated per step, freed when the next step drops .grad
-    for _ in range(2):
+    for _ in range(2 + settle_steps):       # (settle_steps: main's --settle-steps, halved — a C5 step is 1.5 C3 steps long)
         step()
     torch.cuda.synchronize()
     plain_wall, plain_ms, plain_alloc, plain_host, plain_gc = timed(max(5, steps // 2))
@@ -871,7 +890,7 @@ def c5_object(S, dev, steps=20):
     # ---- gradient sinks: the per-Gaussian backward writes the seven parameter gradients into one flat buffer
     fg = FlatGrads(t)
     rast.set_grad_sink(fg.sink(), accumulate=False)
-    for _ in range(2):
+    for _ in range(2 + settle_steps):
         step()
     torch.cuda.synchronize()
     ms, per_step, sink_alloc, host_ms, gc_events = timed(steps)           # no stage timers (each costs two event records: ~0.1 ms per step in all)

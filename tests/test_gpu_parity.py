@@ -133,6 +133,16 @@ def test_c2_gauss_fwd_bwd():
     _run_gauss(100_000, 800, 800, 1002, -3.6, 3, (0, 0, 0), antialiasing=True)
 
 
+# ---- a tile grid with more than 255 tiles along one axis: the depth sort cannot carry the tile rectangle packed to 4 x 8 bits beside the
+# index (OrderRect, csrc/gsr_common.hip), key emission gathers the 8-byte rectangle through the sorted index instead (emit_tiles_kernel<true>) ----
+def test_surfel_grid_wider_than_255_tiles():
+    _run_surfel(4_000, 4112, 48, 21, -3.2, 3, (0, 0, 0))
+
+
+def test_gauss_grid_taller_than_255_tiles():
+    _run_gauss(4_000, 40, 4104, 22, -3.2, 3, (0, 0, 0), antialiasing=True)
+
+
 # ---- the per-Gaussian kernels store their AoS rows wave by wave (64 rows through LDS): Gaussian counts that end inside a wave,
 # exactly at one, one past it, and SH tensors whose rows are not 16 coefficients long (the row-by-row fall-back) ----
 @pytest.mark.gpu
