@@ -62,6 +62,7 @@ static int g_opt_cull = 1;
 int option_cull() { return g_opt_cull; }
 static int g_opt_dev = 0;
 int option_dev() { return g_opt_dev; }
+static int g_opt_emit_items = 0;   // 0: by the Gaussian count (EMIT_ITEMS2_FROM); 1 / 2: forced (tests)
 static int g_opt_mailbox = 1;
 static int option_mailbox() { return g_opt_mailbox; }
 static int g_opt_sort_driver = GSR_ONESWEEP_DRIVER;
@@ -315,7 +316,13 @@ __device__ __forceinline__ unsigned long long emit_peek(unsigned long long* p) {
 // decoupled look-back over the workgroups in front, wave-parallel), instead of a rocPRIM inclusive_scan in front of this kernel: that
 // scan read tiles_touched through the depth order (a random 4-byte gather per Gaussian) and cost two dispatches, 19 us at C3 and 97 us
 // at C5; the count is the area of the tile rectangle, which this kernel gathers anyway (culled Gaussians carry an empty rectangle).
-template <bool GATHER>
+// EMIT_ITEMS: Gaussians per thread (consecutive positions of the depth order).  Two halve the number of workgroups and of look-back hops but
+// double what a workgroup does between its ticket and its last store: emission 0.041 -> 0.060 ms at C3 (977 workgroups: two rounds over the
+// chip become one, twice as long) and 0.116 -> 0.101 ms at C5 (4883 workgroups: ten rounds become five) — chosen by the Gaussian count.
+#ifndef EMIT_ITEMS2_FROM
+#define EMIT_ITEMS2_FROM 3000000
+#endif
+template <bool GATHER, int EMIT_ITEMS>
 __global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const unsigned long long* __restrict__ order, const uint32_t* __restrict__ rect,
                                                          unsigned long long* __restrict__ scan_state, uint32_t* __restrict__ ticket,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals, uint32_t tiles_x,
@@ -332,32 +339,45 @@ __global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uns
 	if (threadIdx.x == 0) s_bid = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__syncthreads();
 	const int bid = (int)s_bid;
-	const int i = bid * EMIT_BLOCK + threadIdx.x;
+	const size_t gtid = (size_t)bid * EMIT_BLOCK + threadIdx.x;       // for the grid-stride clears below
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	// index and rectangle of the Gaussian at position i of the depth order: one coalesced 8-byte load (OrderRect); the area of the
-	// rectangle is the number of instances (tiles_touched)
-	const bool valid = i < P;
-	uint32_t idx = 0u, x0 = 0u, y0 = 0u, x1 = 0u, y1 = 0u;
-	if (valid) {
-		const unsigned long long ov = order[i];
-		idx = (uint32_t)ov;
-		if (GATHER) {
-			const uint2 r = reinterpret_cast<const uint2*>(rect)[idx];
-			x0 = r.x & 0xFFFFu; y0 = r.x >> 16; x1 = r.y & 0xFFFFu; y1 = r.y >> 16;
-		} else {
-			const uint32_t hi = (uint32_t)(ov >> 32);
-			x0 = hi & 0xFFu; y0 = (hi >> 8) & 0xFFu; x1 = (hi >> 16) & 0xFFu; y1 = hi >> 24;
-		}
+	// index and rectangle of the Gaussians at positions i0 .. i0 + EMIT_ITEMS - 1 of the depth order: one coalesced load of 8 bytes each
+	// (OrderRect); the area of a rectangle is the number of instances (tiles_touched)
+	const int i0 = (bid * EMIT_BLOCK + (int)threadIdx.x) * EMIT_ITEMS;
+	uint32_t idx[EMIT_ITEMS], x0[EMIT_ITEMS], y0[EMIT_ITEMS], x1[EMIT_ITEMS], y1[EMIT_ITEMS], cnt[EMIT_ITEMS];
+	unsigned long long ov[EMIT_ITEMS];
+	if (EMIT_ITEMS == 2 && i0 + 1 < P) {       // (order is 16-byte aligned: carve_geom; i0 is even)
+		const ulonglong2 o2 = *reinterpret_cast<const ulonglong2*>(order + i0);
+		ov[0] = o2.x; ov[EMIT_ITEMS - 1] = o2.y;
+	} else {
+#pragma unroll
+		for (int e = 0; e < EMIT_ITEMS; e++) ov[e] = i0 + e < P ? order[i0 + e] : 0ull;
 	}
-	const uint32_t cnt = (x1 - x0) * (y1 - y0);
+	uint32_t mine = 0u;
+#pragma unroll
+	for (int e = 0; e < EMIT_ITEMS; e++) {
+		idx[e] = (uint32_t)ov[e];
+		x0[e] = y0[e] = x1[e] = y1[e] = 0u;
+		if (i0 + e < P) {
+			if (GATHER) {
+				const uint2 r = reinterpret_cast<const uint2*>(rect)[idx[e]];
+				x0[e] = r.x & 0xFFFFu; y0[e] = r.x >> 16; x1[e] = r.y & 0xFFFFu; y1[e] = r.y >> 16;
+			} else {
+				const uint32_t hi = (uint32_t)(ov[e] >> 32);
+				x0[e] = hi & 0xFFu; y0[e] = (hi >> 8) & 0xFFu; x1[e] = (hi >> 16) & 0xFFu; y1[e] = hi >> 24;
+			}
+		}
+		cnt[e] = (x1[e] - x0[e]) * (y1[e] - y0[e]);
+		mine += cnt[e];
+	}
 	// (the forward tile kernel only writes the blend masks of the batches it reaches: the rest must read as "nothing blended")
-	for (size_t t = (size_t)i; t < blend_words; t += (size_t)gridDim.x * EMIT_BLOCK) blend_mask[t] = 0ull;
+	for (size_t t = gtid; t < blend_words; t += (size_t)gridDim.x * EMIT_BLOCK) blend_mask[t] = 0ull;
 	// the tile ranges (tile_ranges_kernel fills the non-empty ones after the sort) and the look-back state of the tile-id
 	// sort that follows are cleared here: a dispatch of its own costs ~5 us whatever it does
-	for (uint32_t t = (uint32_t)i; t < tiles; t += gridDim.x * EMIT_BLOCK) ranges[t] = make_uint2(0u, 0u);
-	sort_clear_region(sort_clear, sort_clear_bytes, (size_t)i, (size_t)gridDim.x * EMIT_BLOCK);
-	// ---- scan of the counts: inside the wave, across the four waves, across the workgroups in front
-	uint32_t incl = cnt;
+	for (uint32_t t = (uint32_t)gtid; t < tiles; t += gridDim.x * EMIT_BLOCK) ranges[t] = make_uint2(0u, 0u);
+	sort_clear_region(sort_clear, sort_clear_bytes, gtid, (size_t)gridDim.x * EMIT_BLOCK);
+	// ---- scan of the counts: inside the wave, across the waves, across the workgroups in front
+	uint32_t incl = mine;
 #pragma unroll
 	for (uint32_t o = 1; o < 64; o <<= 1) {
 		const uint32_t v = __shfl_up(incl, o, 64);
@@ -397,32 +417,36 @@ __global__ void __launch_bounds__(EMIT_BLOCK) emit_tiles_kernel(int P, const uns
 	__syncthreads();
 	uint32_t wbase = s_base;
 	for (uint32_t w = 0; w < wave; w++) wbase += s_wsum[w];
-	const uint32_t off = wbase + incl - cnt;
-	// small Gaussians (the mean is 4 instances): one thread writes its own short run
-	if (cnt != 0u && cnt <= EMIT_BIG) {
-		uint32_t o = off;
-		for (uint32_t y = y0; y < y1; y++)
-			for (uint32_t x = x0; x < x1; x++) {
-				tile_keys[o] = y * tiles_x + x;
-				vals[o] = idx;
-				o++;
-			}
-	}
-	// large ones (a near Gaussian covers up to every tile of the image; one thread looping over thousands of instances
-	// was the whole tail of this kernel) are emitted by all 64 lanes of the wave, 256 contiguous bytes per store
-	unsigned long long big = __ballot(cnt > EMIT_BIG);
-	while (big) {
-		const int src = __ffsll((long long)big) - 1;
-		big &= big - 1;
-		const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, src), b_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
-		const uint32_t b_idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, src);
-		const uint32_t b_x0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, src), b_y0 = (uint32_t)__builtin_amdgcn_readlane((int)y0, src);
-		const uint32_t b_w = (uint32_t)__builtin_amdgcn_readlane((int)(x1 - x0), src);
-		for (uint32_t q = lane; q < b_cnt; q += 64u) {
-			const uint32_t dy = q / b_w, dx = q - dy * b_w;   // emission order inside a Gaussian: y outer / x inner
-			tile_keys[b_off + q] = (b_y0 + dy) * tiles_x + (b_x0 + dx);
-			vals[b_off + q] = b_idx;
+	uint32_t off = wbase + incl - mine;
+#pragma unroll
+	for (int e = 0; e < EMIT_ITEMS; e++) {
+		// small Gaussians (the mean is 4 instances): one thread writes its own short run
+		if (cnt[e] != 0u && cnt[e] <= EMIT_BIG) {
+			uint32_t o = off;
+			for (uint32_t y = y0[e]; y < y1[e]; y++)
+				for (uint32_t x = x0[e]; x < x1[e]; x++) {
+					tile_keys[o] = y * tiles_x + x;
+					vals[o] = idx[e];
+					o++;
+				}
 		}
+		// large ones (a near Gaussian covers up to every tile of the image; one thread looping over thousands of instances
+		// was the whole tail of this kernel) are emitted by all 64 lanes of the wave, 256 contiguous bytes per store
+		unsigned long long big = __ballot(cnt[e] > EMIT_BIG);
+		while (big) {
+			const int src = __ffsll((long long)big) - 1;
+			big &= big - 1;
+			const uint32_t b_off = (uint32_t)__builtin_amdgcn_readlane((int)off, src), b_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt[e], src);
+			const uint32_t b_idx = (uint32_t)__builtin_amdgcn_readlane((int)idx[e], src);
+			const uint32_t b_x0 = (uint32_t)__builtin_amdgcn_readlane((int)x0[e], src), b_y0 = (uint32_t)__builtin_amdgcn_readlane((int)y0[e], src);
+			const uint32_t b_w = (uint32_t)__builtin_amdgcn_readlane((int)(x1[e] - x0[e]), src);
+			for (uint32_t q = lane; q < b_cnt; q += 64u) {
+				const uint32_t dy = q / b_w, dx = q - dy * b_w;   // emission order inside a Gaussian: y outer / x inner
+				tile_keys[b_off + q] = (b_y0 + dy) * tiles_x + (b_x0 + dx);
+				vals[b_off + q] = b_idx;
+			}
+		}
+		off += cnt[e];
 	}
 }
 
@@ -618,8 +642,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
 		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
 		uint32_t* ticket = reinterpret_cast<uint32_t*>(geom.emit_state + (geom.emit_state_bytes / sizeof(unsigned long long) - 1));   // last state word: never a scan position
-		auto emit = rect_packs(tiles_x, tiles_y) ? emit_tiles_kernel<false> : emit_tiles_kernel<true>;
-		emit<<<(P + EMIT_BLOCK - 1) / EMIT_BLOCK, EMIT_BLOCK, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, ticket, b.tile_keys_unsorted,
+		const int items = g_opt_emit_items ? g_opt_emit_items : (P >= EMIT_ITEMS2_FROM ? 2 : 1);
+		auto emit = rect_packs(tiles_x, tiles_y) ? (items == 2 ? emit_tiles_kernel<false, 2> : emit_tiles_kernel<false, 1>)
+		                                         : (items == 2 ? emit_tiles_kernel<true, 2> : emit_tiles_kernel<true, 1>);
+		emit<<<(P + EMIT_BLOCK * items - 1) / (EMIT_BLOCK * items), EMIT_BLOCK, 0, stream>>>(P, geom.order, geom.rect, geom.emit_state, ticket, b.tile_keys_unsorted,
 		                                                       b.vals_unsorted, (uint32_t)tiles_x, img.ranges, tiles, b.sort_temp, clear_bytes, b.blend_mask,
 		                                                       16 * b.mask_stride); }
 		GSR_LAUNCH_CHECK(debug, stream);
@@ -695,6 +721,7 @@ extern "C" int gsr_version(void) { return GSR_ABI_VERSION; }
 extern "C" int gsr_set_option(const char* name, int value) {
 	if (std::string(name) == "cull") { g_opt_cull = value ? 1 : 0; return 0; }
 	if (std::string(name) == "dev") { g_opt_dev = value; return 0; }
+	if (std::string(name) == "emit_items") { g_opt_emit_items = (value == 1 || value == 2) ? value : 0; return 0; }   // Gaussians per thread of key emission; 0 = by size
 	if (std::string(name) == "mailbox") { g_opt_mailbox = value ? 1 : 0; return 0; }   // 0: num_rendered comes back through a copy + event (round 2)
 	if (std::string(name) == "sort_driver") { g_opt_sort_driver = value ? 1 : 0; return 0; }   // 0: public rocprim::radix_sort_pairs everywhere
 	set_error("gsr_set_option: unknown option '%s'", name);

@@ -438,7 +438,9 @@ int gsr_adam_step_range(float* param, const float* grad, float* exp_avg, float* 
 #define GSR_STAGE_COUNT 18
 /* Test/diagnostic switches.  "cull" (default 1): per-wave footprint culling inside the tile kernels (each wave votes
  * which list entries can reach its 8x8 pixel block at all); outputs are bit-identical with 0 and 1, it only skips
- * (wave, Gaussian) pairs that cannot blend.  "dev" (default 0): development ablation bits, not for production. */
+ * (wave, Gaussian) pairs that cannot blend.  "dev" (default 0): development ablation bits, not for production.  "emit_items" (default 0 =
+ * chosen by the Gaussian count): 1 / 2 force the Gaussians per thread of key emission (tests).  "mailbox", "sort_driver" (default 1): 0 = the
+ * round-2 read-back of num_rendered / the public rocPRIM sort entry points. */
 int gsr_set_option(const char* name, int value);
 int gsr_profile_enable(int on);
 int gsr_profile_collect(float* ms_out /* [GSR_STAGE_COUNT] */, int* launches_out /* [GSR_STAGE_COUNT] */);

@@ -143,6 +143,20 @@ def test_gauss_grid_taller_than_255_tiles():
     _run_gauss(4_000, 40, 4104, 22, -3.2, 3, (0, 0, 0), antialiasing=True)
 
 
+# ---- key emission with two Gaussians per thread (chosen from 3 M Gaussians up; forced here), on both forms of the tile rectangle ----
+@pytest.mark.parametrize("variant,P,W,H", [("S", 5_000, 200, 136), ("G", 4_097, 256, 256), ("S", 3_001, 4112, 48)])
+def test_key_emission_two_gaussians_per_thread(variant, P, W, H):
+    import _gsr
+    try:
+        _gsr.set_option("emit_items", 2)
+        if variant == "S":
+            _run_surfel(P, W, H, 31, -3.0, 3, (0, 0, 0), backward=False)
+        else:
+            _run_gauss(P, W, H, 32, -3.0, 3, (0, 0, 0), antialiasing=True, backward=False)
+    finally:
+        _gsr.set_option("emit_items", 0)
+
+
 # ---- the per-Gaussian kernels store their AoS rows wave by wave (64 rows through LDS): Gaussian counts that end inside a wave,
 # exactly at one, one past it, and SH tensors whose rows are not 16 coefficients long (the row-by-row fall-back) ----
 @pytest.mark.gpu
