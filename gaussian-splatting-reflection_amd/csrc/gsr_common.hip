@@ -115,6 +115,13 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 #define TILE_SORT_BS 1024
 #endif
 #define TILE_SORT_SHAPE TILE_SORT_BS, TILE_SORT_IPT, TILE_SORT_BITS
+// From this many instances on the tile sort uses half as many items per thread (twice as many workgroups): measured at C5 (15.2 M instances),
+// whole sort stage 0.501 -> 0.485-0.495 ms; at C3 (3.95 M) the large shape wins by 12-30 us (profiles/r04_ab_tile_sort_shapes_emit_block.txt).
+#ifndef TILE_SORT_SMALL_FROM
+#define TILE_SORT_SMALL_FROM 9000000
+#endif
+#define TILE_SORT_SHAPE_SMALL TILE_SORT_BS, (TILE_SORT_IPT / 2), TILE_SORT_BITS
+static bool tile_sort_small(size_t R) { return R >= (size_t)TILE_SORT_SMALL_FROM; }
 static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
 
 // What the depth sort carries as its VALUE (round 4): the Gaussian's index (low word) and its tile rectangle packed to 4 x 8 bits
@@ -166,9 +173,14 @@ static size_t depth_sort_bytes(size_t P) {
 size_t scan_temp_bytes(size_t P) { return scan_part_bytes(P) + depth_sort_bytes(P); }
 size_t sort_temp_bytes(size_t R, int end_bit) {
 	size_t bytes = 0, pub = 0;
-	if (R <= SORT_MAX_ITEMS)
-		(void)onesweep_sort_pairs<TILE_SORT_SHAPE>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, R,
-		                                           0u, (unsigned)end_bit, 0);
+	if (R <= SORT_MAX_ITEMS) {
+		if (tile_sort_small(R))
+			(void)onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+			                                                 R, 0u, (unsigned)end_bit, 0);
+		else
+			(void)onesweep_sort_pairs<TILE_SORT_SHAPE>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, R,
+			                                           0u, (unsigned)end_bit, 0);
+	}
 	(void)rocprim::radix_sort_pairs<SortConfig>(nullptr, pub, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, R, 0,
 	                                            end_bit, 0, false);
 	return std::max(bytes, pub);
@@ -640,7 +652,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
-		const size_t clear_bytes = own_sort ? onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit) : 0;
+		const size_t clear_bytes = !own_sort ? 0 : tile_sort_small((size_t)R) ? onesweep_cleared_bytes<TILE_SORT_SHAPE_SMALL>((size_t)R, 0u, (unsigned)bit)
+		                                                                       : onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit);
 		uint32_t* ticket = reinterpret_cast<uint32_t*>(geom.emit_state + (geom.emit_state_bytes / sizeof(unsigned long long) - 1));   // last state word: never a scan position
 		const int items = g_opt_emit_items ? g_opt_emit_items : (P >= EMIT_ITEMS2_FROM ? 2 : 1);
 		auto emit = rect_packs(tiles_x, tiles_y) ? (items == 2 ? emit_tiles_kernel<false, 2> : emit_tiles_kernel<false, 1>)
@@ -651,7 +664,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
-		if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS)
+		if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS && tile_sort_small((size_t)R))
+			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
+			                                                        (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
+		else if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS)
 			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
 			                                                  (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
 		else
