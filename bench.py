@@ -294,7 +294,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    settle_steps = settle(step, args, len(my_views))
+    settle_steps = settle(step, args, -(-views_total // world))     # (the same count on every rank: each step holds a collective)
     for _ in range(args.warmup):
         step()
     # the timed region: exactly K steps between two barrier + synchronize brackets, nothing else on the stream (no events, no
@@ -336,7 +336,7 @@ def main():
         for _ in range(2):                     # (the first steps of the other mode size new scratch buffers)
             step()
         sync_all()
-        settle(step, args, len(my_views))      # (the collect above left the GPU idle: without this the five launches below are the slow ones of the ramp)
+        settle(step, args, -(-views_total // world))   # (the collect above left the GPU idle: without this the five launches below are the slow ones of the ramp)
         _gsr.profile_enable(True)
         for _ in range(5):
             step()
@@ -686,7 +686,7 @@ def full_train_step(args, scene, views, S, dev, means2D, sync_all, dist_on, worl
             st.optimizer.step()
         return loss
 
-    settle(lambda: full_step(1), args, len(views))
+    settle(lambda: full_step(1), args, -(-views_total // world))
     for i in range(args.warmup):
         full_step(i + 1)
     sync_all()

@@ -144,7 +144,12 @@ hipError_t onesweep_sort_pairs(void* temp, size_t& bytes, const uint32_t* keys_i
 	}
 	const SortOffset* counts = ext_counts;
 	if (counts == nullptr) {
-		sort_histogram_kernel<BS, IPT, BITS><<<blocks, BS, 0, stream>>>(keys_in, digits, size, full_blocks, begin_bit, end_bit);
+		// the histogram has its own items per thread: with the passes' 8 (tile sort at C5 sizes) it launches twice the workgroups, each of
+		// which flushes 2^BITS counters per place with atomics — 39 us against 25 us for 15 M keys
+		constexpr unsigned HIPT = IPT < 16 ? 16 : IPT, hist_items = BS * HIPT;
+		const unsigned hist_blocks = (size + hist_items - 1) / hist_items;
+		const unsigned hist_full = size % hist_items == 0 ? hist_blocks : hist_blocks - 1;
+		sort_histogram_kernel<BS, HIPT, BITS><<<hist_blocks, BS, 0, stream>>>(keys_in, digits, size, hist_full, begin_bit, end_bit);
 		counts = digits;
 	}
 
