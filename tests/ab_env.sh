@@ -1,4 +1,4 @@
-# Development aid (GPU box): bench.py with and without one environment switch, interleaved.   bash tests/ab_env.sh GSR_PREFILL 0 [bench args]
+# Development aid (GPU box): bench.py with and without one environment switch, interleaved.   bash tests/ab_env.sh GSR_DEV 4 [bench args]
 #   -> gpurun_out/ab_env_<VAR>.txt   (lines: "<VAR>=<value|unset> ms/step fwd c5")
 var=$1; val=$2; shift 2
 out=gpurun_out/ab_env_$var.txt
