@@ -121,7 +121,11 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 #define TILE_SORT_SMALL_FROM 9000000
 #endif
 #define TILE_SORT_SHAPE_SMALL TILE_SORT_BS, (TILE_SORT_IPT / 2), TILE_SORT_BITS
+// ... and, where the tile ids fit 14 bits (up to 16 384 tiles: still two passes), 7-bit digits: sort stage at C5 0.475-0.487 -> 0.444-0.471 ms
+// (three interleaved runs, profiles/r04_ab_tile_sort_7bit_digits_c5.txt); at C3 sizes 7 against 8 bits was +-2 % either way (round 3).
+#define TILE_SORT_SHAPE_SMALL7 TILE_SORT_BS, (TILE_SORT_IPT / 2), 7
 static bool tile_sort_small(size_t R) { return R >= (size_t)TILE_SORT_SMALL_FROM; }
+static bool tile_sort_7bit(size_t R, int end_bit) { return tile_sort_small(R) && end_bit > 7 && end_bit <= 14; }
 static const size_t SORT_MAX_ITEMS = ((size_t)1 << 30) - 1;   // gsr_sort.hpp handles one rocPRIM batch; beyond it rocPRIM itself
 
 // What the depth sort carries as its VALUE (round 4): the Gaussian's index (low word) and its tile rectangle packed to 4 x 8 bits
@@ -174,7 +178,10 @@ size_t scan_temp_bytes(size_t P) { return scan_part_bytes(P) + depth_sort_bytes(
 size_t sort_temp_bytes(size_t R, int end_bit) {
 	size_t bytes = 0, pub = 0;
 	if (R <= SORT_MAX_ITEMS) {
-		if (tile_sort_small(R))
+		if (tile_sort_7bit(R, end_bit))
+			(void)onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL7>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+			                                                  R, 0u, (unsigned)end_bit, 0);
+		else if (tile_sort_small(R))
 			(void)onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
 			                                                 R, 0u, (unsigned)end_bit, 0);
 		else
@@ -652,7 +659,8 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 	if (R > 0) {
 		{ StageTimer st_(GSR_STAGE_EMIT_KEYS, stream);
 		const bool own_sort = option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS;
-		const size_t clear_bytes = !own_sort ? 0 : tile_sort_small((size_t)R) ? onesweep_cleared_bytes<TILE_SORT_SHAPE_SMALL>((size_t)R, 0u, (unsigned)bit)
+		const size_t clear_bytes = !own_sort ? 0 : tile_sort_7bit((size_t)R, bit) ? onesweep_cleared_bytes<TILE_SORT_SHAPE_SMALL7>((size_t)R, 0u, (unsigned)bit)
+		                         : tile_sort_small((size_t)R) ? onesweep_cleared_bytes<TILE_SORT_SHAPE_SMALL>((size_t)R, 0u, (unsigned)bit)
 		                                                                       : onesweep_cleared_bytes<TILE_SORT_SHAPE>((size_t)R, 0u, (unsigned)bit);
 		uint32_t* ticket = reinterpret_cast<uint32_t*>(geom.emit_state + (geom.emit_state_bytes / sizeof(unsigned long long) - 1));   // last state word: never a scan position
 		const int items = g_opt_emit_items ? g_opt_emit_items : (P >= EMIT_ITEMS2_FROM ? 2 : 1);
@@ -664,7 +672,10 @@ int run_binning(gsr_alloc_fn alloc, void* alloc_user, int P, int tiles_x, int ti
 		GSR_LAUNCH_CHECK(debug, stream);
 		size_t sb = b.sort_temp_bytes;
 		{ StageTimer st_(GSR_STAGE_SORT, stream);   // level 2: stable by tile id only
-		if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS && tile_sort_small((size_t)R))
+		if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS && tile_sort_7bit((size_t)R, bit))
+			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL7>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
+			                                                         (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
+		else if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS && tile_sort_small((size_t)R))
 			GSR_HIP_CHECK(onesweep_sort_pairs<TILE_SORT_SHAPE_SMALL>(b.sort_temp, sb, (const uint32_t*)b.tile_keys_unsorted, b.tile_keys,
 			                                                        (const uint32_t*)b.vals_unsorted, b.point_list, (size_t)R, 0u, (unsigned)bit, stream, true));
 		else if (option_sort_driver() && (size_t)R <= SORT_MAX_ITEMS)
