@@ -308,13 +308,17 @@ def main():
         else:
             gc_events.append({"generation": info.get("generation"), "ms": round((time.perf_counter() - gc_t[0]) * 1e3, 2)})
     pygc.callbacks.append(on_gc)
+    host_t = [0.0] * (args.steps + 1)     # host clock at every step boundary (a perf_counter call: ~50 ns; no GPU call, no synchronisation)
     sync_all()
     t0 = time.perf_counter()
+    host_t[0] = t0
     for i in range(args.steps):
         step()
+        host_t[i + 1] = time.perf_counter()
     sync_all()
     dt = time.perf_counter() - t0
     pygc.callbacks.remove(on_gc)
+    host_step_ms = [(host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps)]
     # the same K steps again, instrumented: one event per step (percentiles) and the library's per-stage hipEvent timers
     _gsr.profile_enable(True)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -527,6 +531,9 @@ def main():
                                      "fused: the deferred reflection's pixel code runs inside the rasterizer's tile kernels (rasterize_reflect)"},
             "step_ms": percentiles(step_ms),
             "python_gc_in_timed_region": gc_events,
+            "host_ms_per_step_in_timed_region": dict(percentiles(host_step_ms), what="host time inside each timed step's calls (every step has one "
+                                                     "host-GPU rendezvous, the num_rendered read-back): a max far above the median is a step in which "
+                                                     "the HOST thread was held up, and the GPU with it"),
             "render_fps_forward_only": round(1e3 / fwd_ms, 2), "forward_ms": round(fwd_ms, 4), "forward_step_ms": percentiles(fwd_step_ms),
             "stage_ms_per_view": {k: round(v[0] / max(1, args.steps * nv), 4) for k, v in stages.items() if v[1] > 0},
             "instrumented": "step_ms and stage_ms_per_view come from a second pass of the same K steps with one event per step and the library's "
